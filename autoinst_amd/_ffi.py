@@ -1,0 +1,94 @@
+"""ctypes binding of ``libautoinst_hip.so`` (C ABI in ``include/autoinst_hip.h``).
+
+There is no CPU fallback: if the library is missing or cannot be loaded the import of the
+compute entry points raises, and every compute call needs a gfx950 device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libautoinst_hip.so")
+
+AI_OK = 0
+AI_MEM_HOST, AI_MEM_DEVICE = 0, 1
+NUM_CUTS = 10
+
+# every symbol include/autoinst_hip.h declares (tests check the library exports each one)
+SYMBOLS = (
+    "ai_version", "ai_last_error", "ai_ctx_create", "ai_ctx_destroy", "ai_affinity_build",
+    "ai_csr_from_host", "ai_csr_dims", "ai_csr_export", "ai_csr_free", "ai_ncut", "ai_fiedler",
+    "ai_sweep", "ai_lsym_apply", "ai_bench_spmv",
+)
+
+
+class NcutOpts(C.Structure):
+    _fields_ = [("tol", C.c_double), ("max_iter", C.c_int32), ("check_every", C.c_int32), ("reserved", C.c_int32)]
+
+
+class NcutStats(C.Structure):
+    _fields_ = [
+        ("levels", C.c_int64), ("lanczos_solves", C.c_int64), ("null_solves", C.c_int64),
+        ("lanczos_steps", C.c_int64), ("spmv_rows", C.c_int64), ("spmv_nnz", C.c_int64),
+        ("unconverged", C.c_int64), ("n_groups", C.c_int64),
+        ("ms_total", C.c_double), ("ms_eigen", C.c_double), ("ms_spmv", C.c_double),
+        ("ms_sweep", C.c_double), ("ms_rebuild", C.c_double), ("max_resid", C.c_double),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class AutoinstHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises ``AutoinstHipError`` when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AutoinstHipError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C autoinst_amd/csrc`).  autoinst_amd has no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. the ROCm runtime is absent
+        raise AutoinstHipError(f"cannot load {LIB_PATH}: {e}") from e
+    vp, i64, i32, dbl = C.c_void_p, C.c_int64, C.c_int32, C.c_double
+    P = C.POINTER
+    lib.ai_version.restype = C.c_int
+    lib.ai_last_error.restype = C.c_char_p
+    lib.ai_ctx_create.argtypes = [C.c_int, P(vp)]
+    lib.ai_ctx_destroy.argtypes = [vp]
+    lib.ai_affinity_build.argtypes = [vp, vp, i64, vp, i32, vp, i32, dbl, dbl, dbl, dbl, C.c_int, P(vp)]
+    lib.ai_csr_from_host.argtypes = [vp, i64, vp, vp, vp, P(vp)]
+    lib.ai_csr_dims.argtypes = [vp, P(i64), P(i64)]
+    lib.ai_csr_export.argtypes = [vp, vp, vp, vp, vp]
+    lib.ai_csr_free.argtypes = [vp, vp]
+    lib.ai_ncut.argtypes = [vp, vp, i64, dbl, dbl, P(NcutOpts), vp, P(i32), P(NcutStats)]
+    lib.ai_fiedler.argtypes = [vp, vp, P(NcutOpts), P(dbl), vp, P(i32), P(dbl)]
+    lib.ai_sweep.argtypes = [vp, vp, vp, vp, vp, P(dbl)]
+    lib.ai_lsym_apply.argtypes = [vp, vp, vp, vp]
+    lib.ai_bench_spmv.argtypes = [vp, vp, i32, P(dbl), P(dbl)]
+    for name in SYMBOLS:
+        if name not in ("ai_version", "ai_last_error"):
+            getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str):
+    if status == AI_OK:
+        return
+    msg = load().ai_last_error().decode("utf-8", "replace")
+    if status == -1:
+        raise ValueError(f"{what}: {msg}")
+    if status == -2:
+        raise MemoryError(f"{what}: {msg}")
+    raise AutoinstHipError(f"{what} failed (status {status}): {msg}")

@@ -1,0 +1,421 @@
+// Affinity build on a uniform cell list (cell = radius): radius graph + spatial / TARL / DINO
+// kernels -> CSR on the device.
+//
+// Replaces pipeline/ncuts/ncuts_utils.py:60-67,112-156,159,167 (see include/autoinst_hip.h):
+//   A_ij = 1[d_ij <= r] * exp(-theta t_ij) * exp(-alpha d_ij) * exp(-gamma g_ij),
+//   t_ij = 0 when either TARL row is all-zero, A_ii = 1.
+// The reference forms five dense N x N matrices; here points are Morton-sorted by cell, each
+// point scans its 27 neighbouring cells (count pass, scan, fill pass), and a wave-per-row
+// kernel computes the feature distances only for pairs inside the radius (2*E*F flops
+// instead of 2*N^2*F).
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "ai_common.h"
+
+namespace {
+
+struct Grid {
+  double minx, miny, minz, inv_cell;
+  int nx, ny, nz;
+};
+
+__device__ __forceinline__ uint32_t part1by2(uint32_t x) {
+  x &= 0x3ffu;
+  x = (x ^ (x << 16)) & 0xff0000ffu;
+  x = (x ^ (x << 8)) & 0x0300f00fu;
+  x = (x ^ (x << 4)) & 0x030c30c3u;
+  x = (x ^ (x << 2)) & 0x09249249u;
+  return x;
+}
+
+__device__ __forceinline__ void cell_of(const Grid& g, double x, double y, double z, int& cx, int& cy, int& cz) {
+  cx = (int)floor((x - g.minx) * g.inv_cell);
+  cy = (int)floor((y - g.miny) * g.inv_cell);
+  cz = (int)floor((z - g.minz) * g.inv_cell);
+  cx = min(max(cx, 0), g.nx - 1);
+  cy = min(max(cy, 0), g.ny - 1);
+  cz = min(max(cz, 0), g.nz - 1);
+}
+
+// per-block min / max of the coordinates -> part[block][6]
+__global__ __launch_bounds__(AI_BLOCK) void k_bounds(const double* __restrict__ xyz, int64_t n, double* __restrict__ part) {
+  __shared__ double sm[6][AI_BLOCK / 64];
+  double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+  for (int64_t i = (int64_t)blockIdx.x * AI_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * AI_BLOCK) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const double v = xyz[i * 3 + a];
+      mn[a] = fmin(mn[a], v);
+      mx[a] = fmax(mx[a], v);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mn[a] = fmin(mn[a], __shfl_xor(mn[a], o, 64));
+      mx[a] = fmax(mx[a], __shfl_xor(mx[a], o, 64));
+    }
+  }
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  if (l == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      sm[a][w] = mn[a];
+      sm[3 + a][w] = mx[a];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    double r = sm[threadIdx.x][0];
+    for (int i = 1; i < AI_BLOCK / 64; ++i) r = (threadIdx.x < 3) ? fmin(r, sm[threadIdx.x][i]) : fmax(r, sm[threadIdx.x][i]);
+    part[blockIdx.x * 6 + threadIdx.x] = r;
+  }
+}
+
+__global__ __launch_bounds__(AI_BLOCK) void k_cell_keys(const double* __restrict__ xyz, int64_t n, Grid g,
+                                                        uint32_t* __restrict__ key, int32_t* __restrict__ idx) {
+  const int64_t i = (int64_t)blockIdx.x * AI_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  int cx, cy, cz;
+  cell_of(g, xyz[i * 3], xyz[i * 3 + 1], xyz[i * 3 + 2], cx, cy, cz);
+  key[i] = part1by2((uint32_t)cx) | (part1by2((uint32_t)cy) << 1) | (part1by2((uint32_t)cz) << 2);
+  idx[i] = (int32_t)i;
+}
+
+// sorted SoA coordinates + linear cell id per sorted point
+__global__ __launch_bounds__(AI_BLOCK) void k_gather_sorted(const double* __restrict__ xyz, const int32_t* __restrict__ orig,
+                                                            int64_t n, Grid g, double* __restrict__ X, double* __restrict__ Y,
+                                                            double* __restrict__ Z, int32_t* __restrict__ cellid) {
+  const int64_t p = (int64_t)blockIdx.x * AI_BLOCK + threadIdx.x;
+  if (p >= n) return;
+  const int64_t o = orig[p];
+  const double x = xyz[o * 3], y = xyz[o * 3 + 1], z = xyz[o * 3 + 2];
+  X[p] = x;
+  Y[p] = y;
+  Z[p] = z;
+  int cx, cy, cz;
+  cell_of(g, x, y, z, cx, cy, cz);
+  cellid[p] = (cz * g.ny + cy) * g.nx + cx;
+}
+
+__global__ __launch_bounds__(AI_BLOCK) void k_cell_ranges(const int32_t* __restrict__ cellid, int64_t n,
+                                                          int32_t* __restrict__ cstart, int32_t* __restrict__ cend) {
+  const int64_t p = (int64_t)blockIdx.x * AI_BLOCK + threadIdx.x;
+  if (p >= n) return;
+  const int32_t c = cellid[p];
+  if (p == 0 || cellid[p - 1] != c) cstart[c] = (int32_t)p;
+  if (p == n - 1 || cellid[p + 1] != c) cend[c] = (int32_t)(p + 1);
+}
+
+// cdist's euclidean kernel: sqrt((dx*dx + dy*dy) + dz*dz), every product and sum rounded on
+// its own (no fused multiply-add), so the radius test sees the reference's distance bit for bit
+// (ncuts_utils.py:60-61).
+__device__ __forceinline__ double dist3(double ax, double ay, double az, double bx, double by, double bz) {
+  const double dx = __dsub_rn(ax, bx), dy = __dsub_rn(ay, by), dz = __dsub_rn(az, bz);
+  const double s = __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+  return __dsqrt_rn(s);
+}
+
+// One thread per (sorted) point: walk the 27 neighbouring cells.  FILL = false counts the
+// neighbours within the radius; FILL = true writes their ids and distances.
+template <bool FILL>
+__global__ __launch_bounds__(AI_BLOCK) void k_neighbours(const double* __restrict__ X, const double* __restrict__ Y,
+                                                         const double* __restrict__ Z, const int32_t* __restrict__ cellid,
+                                                         const int32_t* __restrict__ cstart, const int32_t* __restrict__ cend,
+                                                         int64_t n, Grid g, double radius, int32_t* __restrict__ cnt,
+                                                         const int32_t* __restrict__ rowptr, int32_t* __restrict__ col,
+                                                         double* __restrict__ dist) {
+  const int64_t p = (int64_t)blockIdx.x * AI_BLOCK + threadIdx.x;
+  if (p >= n) return;
+  const double x = X[p], y = Y[p], z = Z[p];
+  const int32_t c = cellid[p];
+  const int cx = c % g.nx, cy = (c / g.nx) % g.ny, cz = c / (g.nx * g.ny);
+  int32_t k = 0;
+  int32_t base = 0;
+  if (FILL) base = rowptr[p];
+  for (int dz = -1; dz <= 1; ++dz) {
+    const int zz = cz + dz;
+    if (zz < 0 || zz >= g.nz) continue;
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int yy = cy + dy;
+      if (yy < 0 || yy >= g.ny) continue;
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int xx = cx + dx;
+        if (xx < 0 || xx >= g.nx) continue;
+        const int32_t cc = (zz * g.ny + yy) * g.nx + xx;
+        const int32_t s = cstart[cc];
+        if (s < 0) continue;
+        const int32_t e = cend[cc];
+        for (int32_t q = s; q < e; ++q) {
+          const double d = dist3(x, y, z, X[q], Y[q], Z[q]);
+          if (d <= radius) {
+            if (FILL) {
+              col[base + k] = q;
+              dist[base + k] = d;
+            }
+            ++k;
+          }
+        }
+      }
+    }
+  }
+  if (!FILL) cnt[p] = k;
+}
+
+// all-zero feature row = "no TARL feature for this point" (ncuts_utils.py:143)
+__global__ __launch_bounds__(AI_BLOCK) void k_zero_rows(const double* __restrict__ f, int32_t dim, const int32_t* __restrict__ orig,
+                                                        int64_t n, uint8_t* __restrict__ flag) {
+  const int64_t gid = (int64_t)blockIdx.x * AI_BLOCK + threadIdx.x;
+  const int64_t p = gid >> 4;
+  const int t = (int)(gid & 15);
+  if (p >= n) return;
+  const double* r = f + (int64_t)orig[p] * dim;
+  int any = 0;
+  for (int k = t; k < dim; k += 16) any |= (r[k] != 0.0);
+  any |= __shfl_xor(any, 8, 16);
+  any |= __shfl_xor(any, 4, 16);
+  any |= __shfl_xor(any, 2, 16);
+  any |= __shfl_xor(any, 1, 16);
+  if (t == 0) flag[p] = any ? 0 : 1;
+}
+
+// 16 lanes share one edge: squared Euclidean distance of two feature rows.
+__device__ __forceinline__ double sqdist16(const double* __restrict__ a, const double* __restrict__ b, int dim, int t) {
+  double s = 0.0;
+  for (int k = t; k < dim; k += 16) {
+    const double d = a[k] - b[k];
+    s = fma(d, d, s);
+  }
+  return ai_group16_sum(s);
+}
+
+// One wave per row, four edges in flight (16 lanes each).  On entry val[] holds the spatial
+// distance d_ij; on exit the affinity.  Factors are multiplied in the reference's order
+// (tarl * spatial * dino, ncuts_utils.py:151-156).
+__global__ __launch_bounds__(AI_BLOCK) void k_weights(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                      double* __restrict__ val, const int32_t* __restrict__ orig, int64_t n,
+                                                      const double* __restrict__ tarl, int32_t tdim,
+                                                      const uint8_t* __restrict__ notarl, const double* __restrict__ dino,
+                                                      int32_t ddim, double alpha, double theta, double gamma) {
+  const int64_t row = (int64_t)blockIdx.x * (AI_BLOCK / 64) + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int lane = threadIdx.x & 63;
+  const int grp = lane >> 4, t = lane & 15;
+  const int64_t oi = orig[row];
+  const bool use_t = (theta != 0.0) && tarl != nullptr;
+  const bool use_d = (gamma != 0.0) && dino != nullptr;
+  const bool nti = use_t ? (notarl[row] != 0) : false;
+  const int32_t e0 = rowptr[row], e1 = rowptr[row + 1];
+  for (int32_t eb = e0; eb < e1; eb += 4) {
+    const int32_t e = eb + grp;
+    const bool act = e < e1;
+    const int32_t j = act ? col[e] : (int32_t)row;
+    const int64_t oj = orig[j];
+    double t2 = 0.0, g2 = 0.0;
+    if (use_t) {
+      const bool skip = nti || (notarl[j] != 0);
+      t2 = sqdist16(tarl + oi * tdim, tarl + oj * tdim, tdim, t);
+      if (skip) t2 = 0.0;
+    }
+    if (use_d) g2 = sqdist16(dino + oi * ddim, dino + oj * ddim, ddim, t);
+    if (act && t == 0) {
+      const double d = val[e];
+      double w = 1.0;
+      if (use_t) w = exp(-theta * sqrt(t2));
+      if (alpha != 0.0) w = w * exp(-alpha * d);
+      if (use_d) w = w * exp(-gamma * sqrt(g2));
+      val[e] = w;
+    }
+  }
+}
+
+}  // namespace
+
+// ----------------------------------------------------------------------------- host side
+static int upload_if_host(const double* src, size_t count, int mem_kind, DevBuf<double>& own, const double** dev,
+                          hipStream_t stream) {
+  if (src == nullptr) {
+    *dev = nullptr;
+    return AI_OK;
+  }
+  if (mem_kind == AI_MEM_DEVICE) {
+    *dev = src;
+    return AI_OK;
+  }
+  AI_TRY(own.alloc(count));
+  AI_HIP(hipMemcpyAsync(own.p, src, count * sizeof(double), hipMemcpyHostToDevice, stream));
+  *dev = own.p;
+  return AI_OK;
+}
+
+extern "C" int ai_affinity_build(ai_ctx* ctx, const double* xyz, int64_t n, const double* tarl, int32_t tarl_dim,
+                                 const double* dino, int32_t dino_dim, double alpha, double theta, double gamma,
+                                 double radius, int mem_kind, ai_csr** out) {
+  if (!ctx || !xyz || !out || n <= 0 || !(radius > 0.0)) {
+    ai_set_error("ai_affinity_build: bad argument (ctx/xyz/out null, n <= 0 or radius <= 0)");
+    return AI_ERR_BAD_ARG;
+  }
+  if (n >= (int64_t)1 << 30) {
+    ai_set_error("ai_affinity_build: n = %lld exceeds the int32 row-id range of this build", (long long)n);
+    return AI_ERR_BAD_ARG;
+  }
+  if (gamma != 0.0 && (dino == nullptr || dino_dim <= 0)) {
+    // ncuts_utils.py:126-127 raises ValueError("The length should be longer than 0!")
+    ai_set_error("ai_affinity_build: gamma != 0 needs DINO features (the reference raises ValueError here)");
+    return AI_ERR_BAD_ARG;
+  }
+  if (theta != 0.0 && (tarl == nullptr || tarl_dim <= 0)) {
+    ai_set_error("ai_affinity_build: theta != 0 needs TARL features");
+    return AI_ERR_BAD_ARG;
+  }
+  AI_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  *out = nullptr;
+
+  DevBuf<double> own_xyz, own_tarl, own_dino;
+  const double *d_xyz, *d_tarl, *d_dino;
+  AI_TRY(upload_if_host(xyz, (size_t)n * 3, mem_kind, own_xyz, &d_xyz, st));
+  AI_TRY(upload_if_host(theta != 0.0 ? tarl : nullptr, (size_t)n * (size_t)(tarl_dim > 0 ? tarl_dim : 0), mem_kind, own_tarl, &d_tarl, st));
+  AI_TRY(upload_if_host(gamma != 0.0 ? dino : nullptr, (size_t)n * (size_t)(dino_dim > 0 ? dino_dim : 0), mem_kind, own_dino, &d_dino, st));
+
+  // bounds
+  const int nb = 256;
+  DevBuf<double> part;
+  AI_TRY(part.alloc((size_t)nb * 6));
+  hipLaunchKernelGGL(k_bounds, dim3(nb), dim3(AI_BLOCK), 0, st, d_xyz, n, part.p);
+  AI_KERNEL_CHECK();
+  std::vector<double> hpart((size_t)nb * 6);
+  AI_HIP(hipMemcpyAsync(hpart.data(), part.p, hpart.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  AI_HIP(hipStreamSynchronize(st));
+  double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+  for (int b = 0; b < nb; ++b)
+    for (int a = 0; a < 3; ++a) {
+      if (hpart[b * 6 + a] < mn[a]) mn[a] = hpart[b * 6 + a];
+      if (hpart[b * 6 + 3 + a] > mx[a]) mx[a] = hpart[b * 6 + 3 + a];
+    }
+  for (int a = 0; a < 3; ++a)
+    if (!(mn[a] <= mx[a]) || !(mx[a] - mn[a] < 1e15)) {
+      ai_set_error("ai_affinity_build: coordinates are not finite");
+      return AI_ERR_BAD_ARG;
+    }
+  Grid g;
+  const double cell = radius * (1.0 + 1e-9);  // a hair wider than r: neighbours are always within +-1 cell
+  g.minx = mn[0];
+  g.miny = mn[1];
+  g.minz = mn[2];
+  g.inv_cell = 1.0 / cell;
+  const double ex = (mx[0] - mn[0]) / cell, ey = (mx[1] - mn[1]) / cell, ez = (mx[2] - mn[2]) / cell;
+  if (ex >= 1023.0 || ey >= 1023.0 || ez >= 1023.0) {
+    ai_set_error("ai_affinity_build: extent / radius = (%.0f, %.0f, %.0f) exceeds 1023 cells per axis", ex, ey, ez);
+    return AI_ERR_BAD_ARG;
+  }
+  g.nx = (int)floor(ex) + 1;
+  g.ny = (int)floor(ey) + 1;
+  g.nz = (int)floor(ez) + 1;
+  const int64_t ncell = (int64_t)g.nx * g.ny * g.nz;
+  if (ncell > ((int64_t)1 << 28)) {
+    ai_set_error("ai_affinity_build: %lld grid cells exceed the dense cell-table limit", (long long)ncell);
+    return AI_ERR_BAD_ARG;
+  }
+
+  const unsigned gb = (unsigned)((n + AI_BLOCK - 1) / AI_BLOCK);
+  DevBuf<uint32_t> key, key2;
+  DevBuf<int32_t> idx, cellid, cstart, cend, cnt, scantmp;
+  DevBuf<double> X, Y, Z;
+  DevBuf<uint8_t> notarl;
+  AI_TRY(key.alloc(n));
+  AI_TRY(key2.alloc(n));
+  AI_TRY(idx.alloc(n));
+  hipLaunchKernelGGL(k_cell_keys, dim3(gb), dim3(AI_BLOCK), 0, st, d_xyz, n, g, key.p, idx.p);
+  AI_KERNEL_CHECK();
+
+  // the graph object (rows in Morton-cell order, orig[] maps back)
+  ai_csr* A = new ai_csr();
+  A->n = n;
+  A->nnz = 0;
+  A->rowptr = nullptr;
+  A->col = nullptr;
+  A->val = nullptr;
+  A->orig = nullptr;
+  A->device = ctx->device;
+  auto fail = [&](int s) {
+    ai_csr_free(ctx, A);
+    return s;
+  };
+#define AI_TRYF(expr)                \
+  do {                               \
+    int _s = (expr);                 \
+    if (_s != AI_OK) return fail(_s); \
+  } while (0)
+#define AI_HIPF(expr)                                                                     \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      ai_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return fail((_e == hipErrorOutOfMemory) ? AI_ERR_OOM : AI_ERR_HIP);                \
+    }                                                                                     \
+  } while (0)
+
+  AI_HIPF(hipMalloc((void**)&A->orig, (size_t)n * sizeof(int32_t)));
+  AI_HIPF(hipMalloc((void**)&A->rowptr, (size_t)(n + 1) * sizeof(int32_t)));
+  {
+    size_t tmp_bytes = 0;
+    AI_HIPF(rocprim::radix_sort_pairs(nullptr, tmp_bytes, key.p, key2.p, idx.p, A->orig, (size_t)n, 0, 30, st));
+    DevBuf<uint8_t> tmp;
+    AI_TRYF(tmp.alloc(tmp_bytes));
+    AI_HIPF(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, key.p, key2.p, idx.p, A->orig, (size_t)n, 0, 30, st));
+    AI_HIPF(hipStreamSynchronize(st));  // tmp is released at scope exit
+  }
+  AI_TRYF(X.alloc(n));
+  AI_TRYF(Y.alloc(n));
+  AI_TRYF(Z.alloc(n));
+  AI_TRYF(cellid.alloc(n));
+  AI_TRYF(cstart.alloc(ncell));
+  AI_TRYF(cend.alloc(ncell));
+  AI_TRYF(cnt.alloc(n + 1));
+  AI_TRYF(scantmp.alloc(ai_scan_tmp_elems(n)));
+  hipLaunchKernelGGL(k_gather_sorted, dim3(gb), dim3(AI_BLOCK), 0, st, d_xyz, A->orig, n, g, X.p, Y.p, Z.p, cellid.p);
+  AI_HIPF(hipGetLastError());
+  AI_HIPF(hipMemsetAsync(cstart.p, 0xff, (size_t)ncell * sizeof(int32_t), st));
+  AI_HIPF(hipMemsetAsync(cend.p, 0, (size_t)ncell * sizeof(int32_t), st));
+  hipLaunchKernelGGL(k_cell_ranges, dim3(gb), dim3(AI_BLOCK), 0, st, cellid.p, n, cstart.p, cend.p);
+  AI_HIPF(hipGetLastError());
+  hipLaunchKernelGGL(k_neighbours<false>, dim3(gb), dim3(AI_BLOCK), 0, st, X.p, Y.p, Z.p, cellid.p, cstart.p, cend.p, n, g,
+                     radius, cnt.p, (const int32_t*)nullptr, (int32_t*)nullptr, (double*)nullptr);
+  AI_HIPF(hipGetLastError());
+  AI_TRYF(ai_exclusive_scan_i32(st, cnt.p, A->rowptr, n, scantmp.p));
+  int32_t nnz32 = 0;
+  AI_HIPF(hipMemcpyAsync(&nnz32, A->rowptr + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  AI_HIPF(hipStreamSynchronize(st));
+  if (nnz32 < n) {
+    ai_set_error("ai_affinity_build: internal error, nnz = %d < n (every point is its own neighbour)", nnz32);
+    return fail(AI_ERR_INTERNAL);
+  }
+  A->nnz = nnz32;
+  AI_HIPF(hipMalloc((void**)&A->col, (size_t)A->nnz * sizeof(int32_t)));
+  AI_HIPF(hipMalloc((void**)&A->val, (size_t)A->nnz * sizeof(double)));
+  hipLaunchKernelGGL(k_neighbours<true>, dim3(gb), dim3(AI_BLOCK), 0, st, X.p, Y.p, Z.p, cellid.p, cstart.p, cend.p, n, g,
+                     radius, (int32_t*)nullptr, (const int32_t*)A->rowptr, A->col, A->val);
+  AI_HIPF(hipGetLastError());
+  if (d_tarl) {
+    AI_TRYF(notarl.alloc(n));
+    const unsigned gz = (unsigned)((n * 16 + AI_BLOCK - 1) / AI_BLOCK);
+    hipLaunchKernelGGL(k_zero_rows, dim3(gz), dim3(AI_BLOCK), 0, st, d_tarl, tarl_dim, A->orig, n, notarl.p);
+    AI_HIPF(hipGetLastError());
+  }
+  {
+    const unsigned gw = (unsigned)((n + (AI_BLOCK / 64) - 1) / (AI_BLOCK / 64));
+    hipLaunchKernelGGL(k_weights, dim3(gw), dim3(AI_BLOCK), 0, st, (const int32_t*)A->rowptr, (const int32_t*)A->col, A->val,
+                       (const int32_t*)A->orig, n, d_tarl, tarl_dim, (const uint8_t*)notarl.p, d_dino, dino_dim, alpha, theta,
+                       gamma);
+    AI_HIPF(hipGetLastError());
+  }
+  AI_HIPF(hipStreamSynchronize(st));
+  *out = A;
+  return AI_OK;
+#undef AI_TRYF
+#undef AI_HIPF
+}

@@ -1,0 +1,205 @@
+// Context, error reporting and CSR hand-off (upload / export / free) of libautoinst_hip.so.
+#include <stdarg.h>
+#include <string.h>
+
+#include "ai_common.h"
+
+static thread_local char g_err[1024] = "";
+
+void ai_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* ai_last_error(void) { return g_err; }
+extern "C" int ai_version(void) { return 100; }
+
+extern "C" int ai_ctx_create(int device, ai_ctx** out) {
+  if (!out) {
+    ai_set_error("ai_ctx_create: out is null");
+    return AI_ERR_BAD_ARG;
+  }
+  *out = nullptr;
+  int count = 0;
+  AI_HIP(hipGetDeviceCount(&count));
+  if (device < 0 || device >= count) {
+    ai_set_error("ai_ctx_create: device %d not present (%d visible)", device, count);
+    return AI_ERR_BAD_ARG;
+  }
+  AI_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  AI_HIP(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    ai_set_error("ai_ctx_create: device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    return AI_ERR_BAD_ARG;
+  }
+  ai_ctx* c = new ai_ctx();
+  c->device = device;
+  c->num_cu = prop.multiProcessorCount;
+  AI_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  for (int i = 0; i < 8; ++i) AI_HIP(hipEventCreate(&c->ev[i]));
+  *out = c;
+  return AI_OK;
+}
+
+extern "C" int ai_ctx_destroy(ai_ctx* ctx) {
+  if (!ctx) return AI_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (int i = 0; i < 8; ++i) (void)hipEventDestroy(ctx->ev[i]);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return AI_OK;
+}
+
+extern "C" int ai_csr_free(ai_ctx* ctx, ai_csr* csr) {
+  if (!csr) return AI_OK;
+  if (ctx) (void)hipSetDevice(ctx->device);
+  if (csr->rowptr) (void)hipFree(csr->rowptr);
+  if (csr->col) (void)hipFree(csr->col);
+  if (csr->val) (void)hipFree(csr->val);
+  if (csr->orig) (void)hipFree(csr->orig);
+  delete csr;
+  return AI_OK;
+}
+
+extern "C" int ai_csr_dims(const ai_csr* csr, int64_t* n, int64_t* nnz) {
+  if (!csr) {
+    ai_set_error("ai_csr_dims: csr is null");
+    return AI_ERR_BAD_ARG;
+  }
+  if (n) *n = csr->n;
+  if (nnz) *nnz = csr->nnz;
+  return AI_OK;
+}
+
+extern "C" int ai_csr_from_host(ai_ctx* ctx, int64_t n, const int64_t* indptr, const int32_t* indices, const double* data,
+                                ai_csr** out) {
+  if (!ctx || !indptr || !out || n <= 0) {
+    ai_set_error("ai_csr_from_host: bad argument");
+    return AI_ERR_BAD_ARG;
+  }
+  const int64_t nnz = indptr[n];
+  if (indptr[0] != 0 || nnz < 0 || nnz >= ((int64_t)1 << 31) || n >= ((int64_t)1 << 30) || (nnz > 0 && (!indices || !data))) {
+    ai_set_error("ai_csr_from_host: indptr[0] = %lld, nnz = %lld out of range", (long long)indptr[0], (long long)nnz);
+    return AI_ERR_BAD_ARG;
+  }
+  std::vector<int32_t> rp((size_t)n + 1);
+  for (int64_t i = 0; i <= n; ++i) {
+    if (i > 0 && indptr[i] < indptr[i - 1]) {
+      ai_set_error("ai_csr_from_host: indptr decreases at row %lld", (long long)i);
+      return AI_ERR_BAD_ARG;
+    }
+    rp[(size_t)i] = (int32_t)indptr[i];
+  }
+  for (int64_t e = 0; e < nnz; ++e)
+    if (indices[e] < 0 || indices[e] >= n) {
+      ai_set_error("ai_csr_from_host: column index %d out of range at entry %lld", indices[e], (long long)e);
+      return AI_ERR_BAD_ARG;
+    }
+  AI_HIP(hipSetDevice(ctx->device));
+  ai_csr* A = new ai_csr();
+  A->n = n;
+  A->nnz = nnz;
+  A->rowptr = nullptr;
+  A->col = nullptr;
+  A->val = nullptr;
+  A->orig = nullptr;
+  A->device = ctx->device;
+  hipError_t e1 = hipMalloc((void**)&A->rowptr, (size_t)(n + 1) * sizeof(int32_t));
+  hipError_t e2 = hipMalloc((void**)&A->col, (size_t)(nnz > 0 ? nnz : 1) * sizeof(int32_t));
+  hipError_t e3 = hipMalloc((void**)&A->val, (size_t)(nnz > 0 ? nnz : 1) * sizeof(double));
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+    ai_csr_free(ctx, A);
+    ai_set_error("ai_csr_from_host: device allocation failed");
+    return AI_ERR_OOM;
+  }
+  hipStream_t st = ctx->stream;
+  hipError_t c1 = hipMemcpyAsync(A->rowptr, rp.data(), (size_t)(n + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st);
+  hipError_t c2 = nnz ? hipMemcpyAsync(A->col, indices, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice, st) : hipSuccess;
+  hipError_t c3 = nnz ? hipMemcpyAsync(A->val, data, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, st) : hipSuccess;
+  hipError_t c4 = hipStreamSynchronize(st);
+  if (c1 != hipSuccess || c2 != hipSuccess || c3 != hipSuccess || c4 != hipSuccess) {
+    ai_csr_free(ctx, A);
+    ai_set_error("ai_csr_from_host: copy to device failed");
+    return AI_ERR_HIP;
+  }
+  *out = A;
+  return AI_OK;
+}
+
+namespace {
+__global__ __launch_bounds__(AI_BLOCK) void k_rowlen_to_orig(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ orig,
+                                                             int64_t n, int32_t* __restrict__ len_orig) {
+  const int64_t p = (int64_t)blockIdx.x * AI_BLOCK + threadIdx.x;
+  if (p >= n) return;
+  len_orig[orig[p]] = rowptr[p + 1] - rowptr[p];
+}
+
+// one thread per row: relabel columns to original ids and insertion-sort them ascending
+__global__ __launch_bounds__(AI_BLOCK) void k_export_rows(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                          const double* __restrict__ val, const int32_t* __restrict__ orig,
+                                                          int64_t n, const int32_t* __restrict__ out_ptr, int32_t* __restrict__ out_col,
+                                                          double* __restrict__ out_val) {
+  const int64_t p = (int64_t)blockIdx.x * AI_BLOCK + threadIdx.x;
+  if (p >= n) return;
+  const int32_t s = rowptr[p], e = rowptr[p + 1];
+  const int32_t base = out_ptr[orig[p]];
+  for (int32_t k = s; k < e; ++k) {
+    const int32_t c = orig[col[k]];
+    const double v = val[k];
+    int32_t pos = base + (k - s);
+    while (pos > base && out_col[pos - 1] > c) {
+      out_col[pos] = out_col[pos - 1];
+      out_val[pos] = out_val[pos - 1];
+      --pos;
+    }
+    out_col[pos] = c;
+    out_val[pos] = v;
+  }
+}
+}  // namespace
+
+extern "C" int ai_csr_export(ai_ctx* ctx, const ai_csr* csr, int64_t* indptr, int32_t* indices, double* data) {
+  if (!ctx || !csr || !indptr || (csr->nnz > 0 && (!indices || !data))) {
+    ai_set_error("ai_csr_export: bad argument");
+    return AI_ERR_BAD_ARG;
+  }
+  AI_HIP(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const int64_t n = csr->n, nnz = csr->nnz;
+  std::vector<int32_t> rp((size_t)n + 1);
+  if (!csr->orig) {
+    AI_HIP(hipMemcpyAsync(rp.data(), csr->rowptr, (size_t)(n + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (nnz) {
+      AI_HIP(hipMemcpyAsync(indices, csr->col, (size_t)nnz * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      AI_HIP(hipMemcpyAsync(data, csr->val, (size_t)nnz * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    AI_HIP(hipStreamSynchronize(st));
+  } else {
+    DevBuf<int32_t> len, optr, ocol, tmp;
+    DevBuf<double> oval;
+    AI_TRY(len.alloc(n + 1));
+    AI_TRY(optr.alloc(n + 1));
+    AI_TRY(ocol.alloc(nnz));
+    AI_TRY(oval.alloc(nnz));
+    AI_TRY(tmp.alloc(ai_scan_tmp_elems(n)));
+    const unsigned gb = (unsigned)((n + AI_BLOCK - 1) / AI_BLOCK);
+    hipLaunchKernelGGL(k_rowlen_to_orig, dim3(gb), dim3(AI_BLOCK), 0, st, (const int32_t*)csr->rowptr, (const int32_t*)csr->orig, n, len.p);
+    AI_KERNEL_CHECK();
+    AI_TRY(ai_exclusive_scan_i32(st, len.p, optr.p, n, tmp.p));
+    hipLaunchKernelGGL(k_export_rows, dim3(gb), dim3(AI_BLOCK), 0, st, (const int32_t*)csr->rowptr, (const int32_t*)csr->col,
+                       (const double*)csr->val, (const int32_t*)csr->orig, n, (const int32_t*)optr.p, ocol.p, oval.p);
+    AI_KERNEL_CHECK();
+    AI_HIP(hipMemcpyAsync(rp.data(), optr.p, (size_t)(n + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (nnz) {
+      AI_HIP(hipMemcpyAsync(indices, ocol.p, (size_t)nnz * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      AI_HIP(hipMemcpyAsync(data, oval.p, (size_t)nnz * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    AI_HIP(hipStreamSynchronize(st));
+  }
+  for (int64_t i = 0; i <= n; ++i) indptr[i] = rp[(size_t)i];
+  return AI_OK;
+}

@@ -1,0 +1,135 @@
+// Internal declarations shared by the HIP sources of libautoinst_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/autoinst_hip.h"
+
+// ----------------------------------------------------------------------------- errors
+void ai_set_error(const char* fmt, ...);
+
+#define AI_HIP(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      ai_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return (_e == hipErrorOutOfMemory) ? AI_ERR_OOM : AI_ERR_HIP;                      \
+    }                                                                                     \
+  } while (0)
+
+#define AI_TRY(expr)            \
+  do {                          \
+    int _s = (expr);            \
+    if (_s != AI_OK) return _s; \
+  } while (0)
+
+#define AI_KERNEL_CHECK() AI_HIP(hipGetLastError())
+
+// ----------------------------------------------------------------------------- handles
+struct ai_ctx {
+  int device;
+  hipStream_t stream;
+  hipEvent_t ev[8];
+  int num_cu;
+};
+
+struct ai_csr {
+  int64_t n;
+  int64_t nnz;
+  int32_t* rowptr;  // n + 1 (device)
+  int32_t* col;     // nnz    (device) internal row ids
+  double* val;      // nnz    (device) raw affinities w_ij
+  int32_t* orig;    // n      (device) internal row -> caller's original id; nullptr = identity
+  int device;
+};
+
+// Device buffer that frees itself (workspace of one call).
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t count = 0;
+  DevBuf() {}
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    count = 0;
+  }
+  int alloc(size_t n) {
+    release();
+    if (n == 0) n = 1;
+    hipError_t e = hipMalloc((void**)&p, n * sizeof(T));
+    if (e != hipSuccess) {
+      p = nullptr;
+      ai_set_error("hipMalloc of %zu bytes failed: %s", n * sizeof(T), hipGetErrorString(e));
+      return AI_ERR_OOM;
+    }
+    count = n;
+    return AI_OK;
+  }
+  int ensure(size_t n) { return (n <= count && p) ? AI_OK : alloc(n); }
+};
+
+// ----------------------------------------------------------------------------- scan (ai_scan.hip)
+// out[0..n] = exclusive prefix sums of in[0..n-1]; out[n] = total.  in may alias out.
+// tmp must hold ai_scan_tmp_elems(n) int32.
+size_t ai_scan_tmp_elems(int64_t n);
+int ai_exclusive_scan_i32(hipStream_t stream, const int32_t* in, int32_t* out, int64_t n, int32_t* tmp);
+
+// ----------------------------------------------------------------------------- device helpers
+#ifdef __HIPCC__
+
+#define AI_BLOCK 256
+#define AI_LPR 16   // lanes per row in the row-parallel kernels (neighbour counts are ~30-40)
+
+__device__ __forceinline__ double ai_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double ai_group16_sum(double v) {
+  v += __shfl_xor(v, 8, 16);
+  v += __shfl_xor(v, 4, 16);
+  v += __shfl_xor(v, 2, 16);
+  v += __shfl_xor(v, 1, 16);
+  return v;
+}
+// Every thread of the block returns the same value; fixed summation order -> reproducible.
+__device__ __forceinline__ double ai_block_sum(double v, double* sm /* AI_BLOCK/64 doubles */) {
+  v = ai_wave_sum(v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) sm[w] = v;
+  __syncthreads();
+  double r = 0.0;
+#pragma unroll
+  for (int i = 0; i < AI_BLOCK / 64; ++i) r += sm[i];
+  return r;
+}
+
+// Deterministic start-vector entry in (-1, 1) from the ORIGINAL point id (splitmix64 finaliser).
+// tests/gpu_model.py::start_vector is the same function.
+__device__ __forceinline__ double ai_hash_unit(uint32_t id) {
+  uint64_t x = (uint64_t)id + 0x9E3779B97F4A7C15ull;
+  x ^= x >> 30;
+  x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27;
+  x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return (double)(x >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+}
+
+// blockIdx -> task remap so that each XCD (blocks b, b+8, ... share one) works on one
+// contiguous eighth of the rows: its L2 then holds one slice of the gathered vector.
+__device__ __forceinline__ int ai_xcd_task(int bid, int nblk) {
+  const int per = nblk >> 3;  // blocks per XCD in the evenly divisible part
+  const int body = per << 3;
+  if (bid >= body) return bid;  // ragged tail keeps its identity
+  return (bid & 7) * per + (bid >> 3);
+}
+#endif

@@ -1,0 +1,147 @@
+/*
+ * autoinst_hip.h -- C ABI of libautoinst_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for ONE hot path of artonson/autoinst: the per-chunk pairwise
+ * affinity build and the recursive normalized cut.  The
+ * reference is pure Python (no FFI of its own); each entry point cites the reference
+ * lines it replaces (paths relative to the reference root).  Plain pointers and
+ * sizes only -- no torch / numpy types.  All matrices are float64, like the
+ * reference's arithmetic.
+ *
+ * Threading: an ai_ctx owns one HIP stream and is not thread-safe; the library is
+ * re-entrant across contexts.  One process per GPU for multi-GPU use.
+ * Ownership: the caller owns every array it passes; nothing is retained after a
+ * call returns.  Handles returned here are freed with the matching *_free/destroy.
+ * Errors: every function returns AI_OK (0) or a negative ai_status; the text of the
+ * last error of the calling thread is ai_last_error().
+ */
+#ifndef AUTOINST_HIP_H
+#define AUTOINST_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ai_ctx ai_ctx;
+typedef struct ai_csr ai_csr; /* device-resident symmetric affinity graph */
+
+typedef enum {
+  AI_OK = 0,
+  AI_ERR_BAD_ARG = -1,
+  AI_ERR_OOM = -2,
+  AI_ERR_NO_CONVERGENCE = -3,
+  AI_ERR_HIP = -4,
+  AI_ERR_INTERNAL = -5
+} ai_status;
+
+/* where the caller's buffers live */
+typedef enum { AI_MEM_HOST = 0, AI_MEM_DEVICE = 1 } ai_mem;
+
+#define AI_NUM_CUTS 10 /* pipeline/ncuts/normalized_cut.py:54  get_min_ncut(ev, D, w, 10) */
+
+int ai_version(void);
+const char* ai_last_error(void);
+
+int ai_ctx_create(int device, ai_ctx** out);
+int ai_ctx_destroy(ai_ctx* ctx);
+
+/*
+ * Affinity build.  Replaces pipeline/ncuts/ncuts_utils.py:60-67 (cdist + radius mask +
+ * spatial weights), :125-133 (DINO factor), :135-149 (TARL factor with the all-zero-row
+ * exemption), :151-156 (product), :159 (remove_isolated_points: identity, A_ii = 1) and
+ * :167 (CSR conversion):
+ *     A_ij = 1[d_ij <= radius] * exp(-theta t_ij) * exp(-alpha d_ij) * exp(-gamma g_ij)
+ * xyz: n x 3 row-major; tarl: n x tarl_dim or NULL (theta ignored); dino likewise.
+ * A falsy alpha / theta / gamma (0.0) drops that factor, as the reference's `if CONFIG[..]`.
+ * gamma != 0 with dino == NULL is AI_ERR_BAD_ARG (reference raises ValueError, :126-127).
+ * The graph stays on the device in the library's own (cell-sorted) row order.
+ */
+int ai_affinity_build(ai_ctx* ctx, const double* xyz, int64_t n,
+                      const double* tarl, int32_t tarl_dim,
+                      const double* dino, int32_t dino_dim,
+                      double alpha, double theta, double gamma, double radius,
+                      int mem_kind, ai_csr** out);
+
+/*
+ * Upload a caller-built symmetric CSR (what ncuts_utils.py:167 hands to
+ * normalized_cut at :168).  indptr has n+1 entries.  Row order is kept.
+ */
+int ai_csr_from_host(ai_ctx* ctx, int64_t n, const int64_t* indptr, const int32_t* indices,
+                     const double* data, ai_csr** out);
+
+int ai_csr_dims(const ai_csr* csr, int64_t* n, int64_t* nnz);
+
+/*
+ * Copy the graph out as scipy.sparse.csr_matrix(A) would hold it: rows and columns in
+ * the caller's ORIGINAL point order, column indices ascending within a row.
+ * indptr: n+1, indices/data: nnz (host buffers).
+ */
+int ai_csr_export(ai_ctx* ctx, const ai_csr* csr, int64_t* indptr, int32_t* indices, double* data);
+
+int ai_csr_free(ai_ctx* ctx, ai_csr* csr);
+
+typedef struct {
+  double tol;           /* Ritz residual |beta_m s_m| at which a Lanczos solve stops (default 1e-10) */
+  int32_t max_iter;     /* Lanczos step cap per solve (default 4000) */
+  int32_t check_every;  /* steps between convergence checks on large segments (default 16) */
+  int32_t reserved;
+} ai_ncut_opts;
+
+typedef struct {
+  int64_t levels;          /* frontier levels processed */
+  int64_t lanczos_solves;  /* connected segments solved by Lanczos */
+  int64_t null_solves;     /* disconnected segments given a null-space vector */
+  int64_t lanczos_steps;   /* sum over levels of lock-step Lanczos steps (= fused SpMV launches) */
+  int64_t spmv_rows;       /* rows processed by the SpMV kernel, summed over launches */
+  int64_t spmv_nnz;        /* stored entries processed by the SpMV kernel, summed over launches */
+  int64_t unconverged;     /* solves that hit max_iter before tol */
+  int64_t n_groups;
+  double ms_total;         /* host wall time of the call */
+  double ms_eigen;         /* device time in the Lanczos / Ritz phase (HIP events) */
+  double ms_spmv;          /* device time in the fused SpMV kernel alone (HIP events) */
+  double ms_sweep;         /* device time in min/max + bin + sweep */
+  double ms_rebuild;       /* device time in CC + partition + CSR rebuild */
+  double max_resid;        /* largest accepted Ritz residual */
+} ai_ncut_stats;
+
+/*
+ * Recursive normalized cut.  Replaces pipeline/ncuts/normalized_cut.py:37-63
+ * (normalized_cut), :13-34 (get_min_ncut), :4-11 (cut_cost / ncut_cost) and the
+ * scipy eigsh call at :49.  labels_out[i] (i in the caller's ORIGINAL row order) is the
+ * index of point i's group in the order the reference's recursion emits groups
+ * (mask side first); *n_groups receives their number.  split_lim applies to the top
+ * call only; deeper calls use 0.01 as the reference does (:57-58 rely on the default).
+ * opts / stats may be NULL.
+ */
+int ai_ncut(ai_ctx* ctx, const ai_csr* csr, int64_t num_points_orig, double T, double split_lim,
+            const ai_ncut_opts* opts, int32_t* labels_out, int32_t* n_groups, ai_ncut_stats* stats);
+
+/*
+ * Building blocks exposed for parity tests (top-level call of the recursion only).
+ * ai_fiedler: eigenpair of the 2nd-smallest eigenvalue of L_sym = D^-1/2 (D - W) D^-1/2,
+ *   W = w + I (normalized_cut.py:38-53); ev_out (n, host, original order) has unit norm and
+ *   the library's sign convention (entry of largest magnitude positive).  The graph must be
+ *   connected, else a null-space vector is returned and *lambda2 = 0.
+ * ai_sweep: the 10 threshold costs of normalized_cut.py:13-34 for a caller-given ev
+ *   (host, original order); costs[10], mask_out[n] (uint8), *mcut.
+ * ai_lsym_apply: y = L_sym x (host vectors, original order) through the SpMV kernel.
+ */
+int ai_fiedler(ai_ctx* ctx, const ai_csr* csr, const ai_ncut_opts* opts, double* lambda2,
+               double* ev_out, int32_t* iters, double* resid);
+int ai_sweep(ai_ctx* ctx, const ai_csr* csr, const double* ev, double* costs, uint8_t* mask_out,
+             double* mcut);
+int ai_lsym_apply(ai_ctx* ctx, const ai_csr* csr, const double* x, double* y);
+
+/*
+ * Timing hook for bench.py: runs `reps` fused Lanczos SpMV steps on the whole graph as
+ * one segment and returns the average kernel time (HIP events on the context's stream)
+ * plus the algorithmic byte count of one launch.
+ */
+int ai_bench_spmv(ai_ctx* ctx, const ai_csr* csr, int32_t reps, double* avg_ms, double* bytes_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AUTOINST_HIP_H */

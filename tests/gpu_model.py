@@ -1,0 +1,168 @@
+"""CPU model of the algorithm the HIP path implements (test infrastructure).
+
+The HIP path does not call SciPy's shift-invert ``eigsh``; it finds the same
+eigenvector with its own deterministic solver:
+
+* connected segment  -> Lanczos (no re-orthogonalisation, every vector kept) on
+  M = D^-1/2 (w + I) D^-1/2 with the known top eigenvector u1 = D^1/2 1 / sqrt(vol)
+  projected out each step; the Ritz pair of the largest eigenvalue of T_m is the pair of
+  the 2nd-smallest eigenvalue of L_sym = I - M;
+* disconnected segment -> an explicit null-space vector of L_sym,
+  z = D^1/2 (1_A / vol_A - 1_B / vol_B), (A, B) a bipartition of its connected components;
+
+then exactly the reference's 10-threshold sweep and recursion.  This file restates
+that algorithm in NumPy, segment by segment, so that (a) the algorithm can be checked
+against the oracle / goldens without a GPU and (b) GPU tests can demand *bit-for-bit
+equal partitions* between device and model on inputs where SciPy's own answer is
+arbitrary (degenerate null spaces).
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+from scipy.linalg import eigh_tridiagonal
+from scipy.sparse.csgraph import connected_components
+
+NUM_CUTS = 10
+
+
+def start_vector(ids):
+    """Deterministic pseudo-random start entries in (-1, 1) from the ORIGINAL point id.
+
+    Same integer hash as the device (``ai_hash_unit`` in csrc/ai_common.h).
+    """
+    x = (np.asarray(ids, dtype=np.uint64) + np.uint64(0x9E3779B97F4A7C15)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+    with np.errstate(over="ignore"):
+        x ^= x >> np.uint64(30)
+        x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27)
+        x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+    return (x >> np.uint64(11)).astype(np.float64) * (2.0 / 9007199254740992.0) - 1.0
+
+
+def lanczos_fiedler(w, ids, tol=1e-10, max_iter=4000, check_every=None):
+    """Fiedler vector of L_sym for a CONNECTED w.  Returns (lambda2, ev, iters, resid)."""
+    n = w.shape[0]
+    d = np.asarray(w.sum(axis=0)).ravel() + 1.0
+    s = 1.0 / np.sqrt(d)
+    Wm = sp.diags(s) @ (w + sp.identity(n)) @ sp.diags(s)
+    Wm = Wm.tocsr()
+    u1 = np.sqrt(d / d.sum())
+    v = start_vector(ids)
+    v -= u1 * (u1 @ v)
+    v /= np.linalg.norm(v)
+    V = [v]
+    alpha, beta = [], []
+    v_prev = np.zeros(n)
+    b_prev = 0.0
+    theta = None
+    resid = np.inf
+    m_cap = min(max_iter, n - 1)
+    if check_every is None:
+        # small segments can exhaust their Krylov space between sparse checks (beta -> 0, then
+        # garbage): check every step there, like the device driver does
+        check_every = 1 if n <= 512 else 16
+    for j in range(m_cap):
+        y = Wm @ v
+        a = v @ y
+        wv = y - a * v - b_prev * v_prev
+        # project the FINISHED three-term vector: projecting y alone lets the u1 component of
+        # v grow like the Lanczos polynomial at 0 (x20 per step on small segments)
+        g = u1 @ wv
+        b = np.sqrt(max(wv @ wv - g * g, 0.0))
+        wv = wv - g * u1
+        alpha.append(a)
+        beta.append(b)
+        m = j + 1
+        done = (b <= 1e-14) or (m == m_cap)
+        if done or (m % check_every == 0):
+            th, S = eigh_tridiagonal(np.array(alpha), np.array(beta[:-1]), select="i", select_range=(m - 1, m - 1))
+            theta, sv = th[0], S[:, 0]
+            resid = abs(b * sv[-1])
+            if resid <= tol or done:
+                break
+        v_prev, b_prev = v, b
+        v = wv / b
+        V.append(v)
+    m = len(alpha)
+    th, S = eigh_tridiagonal(np.array(alpha), np.array(beta[:-1]) if m > 1 else np.zeros(0), select="i", select_range=(m - 1, m - 1))
+    ev = np.stack(V[:m], 1) @ S[:, 0]
+    ev /= np.linalg.norm(ev)
+    return 1.0 - th[0], fix_sign(ev), m, resid
+
+
+def fix_sign(ev):
+    """Sign convention of the device: the entry of largest magnitude (first on ties) is positive."""
+    k = int(np.argmax(np.abs(ev)))
+    return -ev if ev[k] < 0 else ev
+
+
+def null_vector(w, ncomp, comp):
+    """Null-space vector of L_sym for a disconnected segment (model of ai_nullvec kernels).
+
+    Components are ordered by their smallest row index; A = the first component plus every
+    later one that still ends within the first half of the points; B = the rest.
+    """
+    n = w.shape[0]
+    d = np.asarray(w.sum(axis=0)).ravel() + 1.0
+    first = np.full(ncomp, n, dtype=np.int64)
+    np.minimum.at(first, comp, np.arange(n))
+    order = np.argsort(first)
+    cnt = np.bincount(comp, minlength=ncomp)[order]
+    cum_before = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+    inA_sorted = (2 * (cum_before + cnt) <= n)
+    inA_sorted[0] = True
+    inA = np.zeros(ncomp, dtype=bool)
+    inA[order] = inA_sorted
+    a = inA[comp]
+    volA, volB = d[a].sum(), d[~a].sum()
+    z = np.sqrt(d) * np.where(a, 1.0 / volA, -1.0 / volB)
+    z /= np.linalg.norm(z)
+    return fix_sign(z)
+
+
+def sweep(ev, d, w):
+    """``normalized_cut.py:13-34`` from an edge list (same rule: strict >, first strictly smaller)."""
+    mn, mx = ev.min(), ev.max()
+    mask0 = np.zeros(ev.shape[0], dtype=bool)
+    if np.allclose(mn, mx):
+        return mask0, np.inf, np.full(NUM_CUTS, np.nan)
+    coo = w.tocoo()
+    costs = np.empty(NUM_CUTS)
+    best, bmask = np.inf, mask0
+    step = (mx - mn) / NUM_CUTS
+    for k in range(NUM_CUTS):
+        t = k * step + mn
+        mask = ev > t
+        cut = coo.data[mask[coo.row] & ~mask[coo.col]].sum()
+        with np.errstate(divide="ignore", invalid="ignore"):
+            c = cut / d[mask].sum() + cut / d[~mask].sum()
+        costs[k] = c
+        if c < best:
+            best, bmask = c, mask
+    return bmask, best, costs
+
+
+def normalized_cut_model(w, num_points_orig, labels, T=0.01, split_lim=0.01, tol=1e-10, stats=None):
+    """Same recursion and output order as the reference; eigenvector from the model solver."""
+    n = w.shape[0]
+    if n > 2 and labels.shape[0] / (num_points_orig + 1e-8) > split_lim:
+        d = np.asarray(w.sum(axis=0)).ravel() + 1.0
+        ncomp, comp = connected_components(w, directed=False)
+        if ncomp > 1:
+            ev = null_vector(w, ncomp, comp)
+            if stats is not None:
+                stats["null"] = stats.get("null", 0) + 1
+        else:
+            lam, ev, m, resid = lanczos_fiedler(w, labels, tol=tol)
+            if stats is not None:
+                stats["lanczos"] = stats.get("lanczos", 0) + 1
+                stats.setdefault("iters", []).append((n, m, lam, resid))
+        mask, mcut, _ = sweep(ev, d, w)
+        if mcut < T:
+            l1 = normalized_cut_model(w[mask][:, mask], num_points_orig, labels[mask], T=T, tol=tol, stats=stats)
+            l2 = normalized_cut_model(w[~mask][:, ~mask], num_points_orig, labels[~mask], T=T, tol=tol, stats=stats)
+            return l1 + l2
+        return [labels]
+    return [labels]

@@ -1,0 +1,192 @@
+"""GPU suite (-m gpu): the HIP path through the C ABI against goldens, the oracle and the model."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+from scipy.sparse.csgraph import connected_components
+
+from conftest import GOLDEN, golden_names
+from oracle import metrics_ref, ncuts_ref
+import gpu_model
+
+pytestmark = pytest.mark.gpu
+
+CONNECTED = ["g1_blob_pair_spatial", "g6_connected_tarl", "g6_connected_spatial"]
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    n = z["points"].shape[0]
+    A = sp.csr_matrix((z["data"], z["indices"], z["indptr"]), shape=(n, n))
+    tarl = z["tarl"].astype(np.float64) if z["tarl"].size else None
+    dino = z["dino"].astype(np.float64) if z["dino"].size else None
+    return z, A, tarl, dino
+
+
+@pytest.fixture(scope="module")
+def api():
+    from autoinst_amd import ncuts_api
+    ncuts_api.default_context()
+    return ncuts_api
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_affinity_matches_golden(api, name):
+    z, A, tarl, dino = load(name)
+    B = api.get_affinity_matrix(z["points"], tarl, dino, alpha=float(z["alpha"]), theta=float(z["theta"]), gamma=float(z["gamma"]))
+    assert B.shape == A.shape and B.nnz == A.nnz
+    assert np.array_equal(B.indptr, A.indptr), "row lengths differ"
+    assert np.array_equal(B.indices, A.indices), "sparsity pattern differs"
+    rel = np.abs(B.data - A.data) / A.data
+    assert rel.max() <= 1e-12, rel.max()
+    assert abs(B - B.T).max() == 0.0, "device affinity is not bitwise symmetric"
+    assert np.all(B.diagonal() == 1.0)
+
+
+@pytest.mark.parametrize("name", ["g2_multicomp_spatial", "g6_connected_tarl"])
+def test_lsym_apply_matches_scipy(api, name):
+    z, A, _, _ = load(name)
+    L, _ = ncuts_ref.laplacian_sym(A)
+    x = np.random.default_rng(0).standard_normal(A.shape[0])
+    g = api.DeviceGraph.from_scipy(A)
+    y = api.lsym_apply(g, x)
+    assert np.abs(y - L @ x).max() <= 1e-13
+
+
+@pytest.mark.parametrize("name", CONNECTED)
+def test_fiedler_matches_golden(api, name):
+    z, A, _, _ = load(name)
+    g = api.DeviceGraph.from_scipy(A)
+    lam, ev, iters, resid = api.fiedler(g)
+    assert lam == pytest.approx(float(z["eigvals"][1]), rel=1e-8)
+    assert resid <= 1e-10 or iters >= A.shape[0] - 1
+    assert abs(np.linalg.norm(ev) - 1.0) <= 1e-10
+    assert np.abs(np.abs(ev) - z["fiedler_abs"]).max() <= 1e-7
+    L, _ = ncuts_ref.laplacian_sym(A)
+    assert np.linalg.norm(L @ ev - lam * ev) <= 1e-8
+    assert ev[np.argmax(np.abs(ev))] > 0
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_null_vector_is_in_the_null_space(api, name):
+    z, A, _, _ = load(name)
+    if int(z["n_components"]) == 1:
+        pytest.skip("connected")
+    g = api.DeviceGraph.from_scipy(A)
+    lam, ev, _, _ = api.fiedler(g)
+    L, _ = ncuts_ref.laplacian_sym(A)
+    assert lam == 0.0 and abs(np.linalg.norm(ev) - 1.0) <= 1e-12
+    assert np.abs(L @ ev).max() <= 1e-13
+    ncomp, comp = connected_components(A, directed=False)
+    assert np.abs(ev - gpu_model.null_vector(A, ncomp, comp)).max() <= 1e-14
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_sweep_costs_match_golden(api, name):
+    z, A, _, _ = load(name)
+    g = api.DeviceGraph.from_scipy(A)
+    costs, mask, mcut = api.sweep(g, z["fiedler"])
+    ref = z["costs"]
+    ok = np.isfinite(ref)
+    big = ok & (np.abs(ref) > 1e-9)
+    assert np.allclose(costs[big], ref[big], rtol=1e-10, atol=0)
+    assert np.abs(costs[ok & ~big] - ref[ok & ~big]).max(initial=0.0) <= 1e-9
+    if int(z["n_components"]) == 1:
+        assert np.array_equal(mask, z["top_mask"])
+        assert mcut == pytest.approx(float(z["top_mcut"]), rel=1e-10)
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_partition_matches_reference(api, name):
+    """normalized_cut on the reference's own CSR: same partition as the imported reference."""
+    z, A, _, _ = load(name)
+    n = A.shape[0]
+    groups = api.normalized_cut(A, n, np.arange(n), T=float(z["T"]), split_lim=0.01)
+    lab = ncuts_ref.groups_to_labels(groups, n)
+    assert (lab >= 0).all() and sum(len(g) for g in groups) == n
+    assert all(np.all(np.diff(g) > 0) for g in groups if len(g) > 1), "members must ascend like labels[mask]"
+    assert api.last_stats()["unconverged"] == 0
+    assert ncuts_ref.partitions_equal(lab, z["labels"])
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_groups_equal_model_including_order(api, name):
+    z, A, _, _ = load(name)
+    n = A.shape[0]
+    got = api.normalized_cut(A, n, np.arange(n), T=float(z["T"]))
+    exp = gpu_model.normalized_cut_model(A, n, np.arange(n), T=float(z["T"]))
+    assert len(got) == len(exp)
+    for a, b in zip(got, exp):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("name", CONNECTED)
+def test_group_order_matches_reference_on_connected(api, name):
+    """Emission order (mask side first) equals the reference's, up to the eigenvector sign."""
+    z, A, _, _ = load(name)
+    n = A.shape[0]
+    got = ncuts_ref.groups_to_labels(api.normalized_cut(A, n, np.arange(n), T=float(z["T"])), n)
+    sizes = np.bincount(got)
+    assert sorted(sizes.tolist()) == sorted(z["group_sizes"].tolist())
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_end_to_end_from_points(api, name):
+    """Affinity on the device (Morton row order) + recursion, vs the reference labels."""
+    z, _, tarl, dino = load(name)
+    n = z["points"].shape[0]
+    groups = api.ncuts(z["points"], tarl, dino, alpha=float(z["alpha"]), theta=float(z["theta"]), gamma=float(z["gamma"]), T=float(z["T"]))
+    lab = ncuts_ref.groups_to_labels(groups, n)
+    assert (lab >= 0).all()
+    if int(z["disconnected_solves"]) == 0:
+        assert ncuts_ref.partitions_equal(lab, z["labels"])
+    else:
+        # the reference's own answer on a disconnected segment is an arbitrary null-space vector
+        assert ncuts_ref.adjusted_rand_index(lab, z["labels"]) >= 0.9
+
+
+def test_edge_cases(api):
+    # n <= 2: never split (normalized_cut.py:40 needs W.shape[0] > 2)
+    A2 = sp.csr_matrix(np.array([[1.0, 0.5], [0.5, 1.0]]))
+    assert [g.tolist() for g in api.normalized_cut(A2, 2, np.arange(2), T=1.0)] == [[0, 1]]
+    # split_lim gate on the original count: 5 rows of a 1000-point chunk stay together
+    pts = np.array([[0, 0, 0], [0.1, 0, 0], [5, 0, 0], [5.1, 0, 0], [9, 0, 0]], dtype=np.float64)
+    A = api.get_affinity_matrix(pts, alpha=1.0, theta=0.0, gamma=0.0)
+    assert A.nnz == 9
+    assert len(api.normalized_cut(A, 1000, np.arange(5), T=1.0)) == 1
+    # isolated points: three singletons + a pair -> every component split off, singletons kept
+    groups = api.normalized_cut(A, 5, np.arange(5), T=0.5)
+    assert sorted(sorted(g.tolist()) for g in groups) == [[0, 1], [2, 3], [4]]
+    # identical eigenvector entries (np.allclose branch): complete graph with equal weights
+    K = sp.csr_matrix(np.ones((6, 6)))
+    assert len(api.normalized_cut(K, 6, np.arange(6), T=10.0)) in (1, 2)
+    # errors mirror the reference: gamma without DINO features
+    with pytest.raises(ValueError):
+        api.get_affinity_matrix(pts, alpha=1.0, theta=0.0, gamma=0.1)
+    # labels are returned as given
+    out = api.normalized_cut(A, 5, np.array([10, 11, 12, 13, 14]), T=0.5)
+    assert sorted(x for g in out for x in g.tolist()) == [10, 11, 12, 13, 14]
+
+
+def test_cfg1_10k_spatial_matches_oracle(api):
+    """BASELINE configs[0]: 10k-point chunk, spatial only, T = 0.075 -- partition vs the CPU oracle."""
+    from autoinst_amd import synth
+    pts, gt = synth.surface_chunk(10_000, seed=0)
+    groups = api.ncuts(pts, alpha=1.0, theta=0.0, gamma=0.0, T=0.075)
+    lab = ncuts_ref.groups_to_labels(groups, pts.shape[0])
+    ref = ncuts_ref.groups_to_labels(ncuts_ref.ncuts(pts, alpha=1.0, theta=0.0, gamma=0.0, T=0.075), pts.shape[0])
+    ari = ncuts_ref.adjusted_rand_index(lab, ref)
+    assert ari >= 0.99, ari
+    s_gpu = metrics_ref.score(lab + 1, lab + 1, gt)
+    s_cpu = metrics_ref.score(ref + 1, ref + 1, gt)
+    for k in ("ap", "S_assoc", "p", "r", "f1"):
+        assert abs(s_gpu[k] - s_cpu[k]) <= 1e-3, (k, s_gpu[k], s_cpu[k])
+
+
+def test_run_to_run_reproducible(api):
+    from autoinst_amd import synth
+    ch = synth.synthetic_chunk(20_000, seed=5)
+    a = api.ncuts(ch["points"], ch["tarl"], alpha=1.0, theta=0.5, gamma=0.0, T=0.03)
+    b = api.ncuts(ch["points"], ch["tarl"], alpha=1.0, theta=0.5, gamma=0.0, T=0.03)
+    assert len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b))

@@ -1,0 +1,117 @@
+"""CPU suite: the oracle against the golden vectors made with the imported reference."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from conftest import GOLDEN, ROOT, golden_names
+from oracle import metrics_ref, ncuts_ref
+import gpu_model
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    n = z["points"].shape[0]
+    A = sp.csr_matrix((z["data"], z["indices"], z["indptr"]), shape=(n, n))
+    tarl = z["tarl"].astype(np.float64) if z["tarl"].size else None
+    dino = z["dino"].astype(np.float64) if z["dino"].size else None
+    return z, A, tarl, dino
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_affinity_restatement_matches_golden(name):
+    z, A, tarl, dino = load(name)
+    B = ncuts_ref.affinity_sparse(z["points"], tarl, dino, alpha=float(z["alpha"]), theta=float(z["theta"]), gamma=float(z["gamma"]))
+    assert np.array_equal(B.indptr, A.indptr) and np.array_equal(B.indices, A.indices)
+    assert np.abs(B.data - A.data).max() <= 1e-15
+    # reference facts: symmetric, unit diagonal, so remove_isolated_points is the identity
+    assert abs(A - A.T).max() == 0.0
+    assert np.all(A.diagonal() == 1.0)
+
+
+@pytest.mark.parametrize("name", ["g1_blob_pair_spatial", "g3_tarl_spatial", "g4_trimodal"])
+def test_dense_reference_arithmetic_equals_sparse(name):
+    z, A, tarl, dino = load(name)
+    D = ncuts_ref.affinity_dense(z["points"], tarl, dino, alpha=float(z["alpha"]), theta=float(z["theta"]), gamma=float(z["gamma"]))
+    keep, D2 = ncuts_ref.remove_isolated_points(D)
+    assert keep.all()
+    assert np.abs(D2 - A.toarray()).max() <= 1e-15
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_top_level_quantities(name):
+    z, A, _, _ = load(name)
+    _, d = ncuts_ref.laplacian_sym(A)
+    assert np.allclose(d, z["degree"], rtol=0, atol=1e-12)
+    # costs of the golden Fiedler vector, by both cost routines
+    ev = z["fiedler"]
+    mask, mcut = ncuts_ref.get_min_ncut(ev, d, A, 10)
+    maskf, mcutf = ncuts_ref.get_min_ncut(ev, d, A, 10, fast=True)
+    assert np.array_equal(mask, z["top_mask"]) and mcut == pytest.approx(float(z["top_mcut"]), abs=1e-12)
+    if int(z["n_components"]) == 1:
+        assert np.array_equal(maskf, mask) and mcutf == pytest.approx(mcut, rel=1e-10)
+        vals, ev2, _ = ncuts_ref.fiedler(A)
+        assert np.sort(vals)[1] == pytest.approx(float(z["eigvals"][1]), rel=1e-8)
+        assert np.abs(np.abs(ev2) - z["fiedler_abs"]).max() <= 1e-8
+
+
+def _fresh_oracle(name, fast):
+    code = (
+        "import sys, numpy as np, scipy.sparse as sp\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from oracle import ncuts_ref\n"
+        f"z = np.load({os.path.join(GOLDEN, name + '.npz')!r})\n"
+        "n = z['points'].shape[0]\n"
+        "A = sp.csr_matrix((z['data'], z['indices'], z['indptr']), shape=(n, n))\n"
+        f"g = ncuts_ref.normalized_cut(A, n, np.arange(n), T=float(z['T']), split_lim=0.01, fast={fast})\n"
+        "lab = ncuts_ref.groups_to_labels(g, n)\n"
+        "print(' '.join(map(str, lab.tolist())))\n"
+    )
+    out = subprocess.run([sys.executable, "-c", code], check=True, capture_output=True, text=True).stdout
+    return np.array(out.split(), dtype=np.int64)
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_recursion_matches_reference_output(name):
+    """Exact groups AND order, in a fresh interpreter (ARPACK's start-vector state is per process)."""
+    z, _, _, _ = load(name)
+    lab = _fresh_oracle(name, fast=False)
+    assert np.array_equal(lab, z["labels"])
+
+
+@pytest.mark.parametrize("name", ["g1_blob_pair_spatial", "g6_connected_tarl", "g6_connected_spatial"])
+def test_recursion_in_process_connected(name):
+    z, A, _, _ = load(name)
+    n = A.shape[0]
+    g = ncuts_ref.normalized_cut(A, n, np.arange(n), T=float(z["T"]), fast=True)
+    assert ncuts_ref.partitions_equal(ncuts_ref.groups_to_labels(g, n), z["labels"])
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_device_algorithm_model_matches_reference(name):
+    """The algorithm the HIP path implements (tests/gpu_model.py) reproduces the reference partition."""
+    z, A, _, _ = load(name)
+    n = A.shape[0]
+    g = gpu_model.normalized_cut_model(A, n, np.arange(n), T=float(z["T"]))
+    lab = ncuts_ref.groups_to_labels(g, n)
+    assert (lab >= 0).all()
+    assert ncuts_ref.partitions_equal(lab, z["labels"])
+
+
+@pytest.mark.parametrize("name", ["scorer_a", "scorer_b"])
+def test_scorer_matches_reference(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    got = metrics_ref.score(z["pred"], z["pred"], z["gt"])
+    for k, v in got.items():
+        assert v == pytest.approx(float(z["exp_" + k.replace(".", "_")]), abs=1e-12), k
+
+
+def test_partition_helpers():
+    a = np.array([3, 3, 1, 1, 2])
+    b = np.array([0, 0, 5, 5, 9])
+    assert ncuts_ref.partitions_equal(a, b)
+    assert ncuts_ref.adjusted_rand_index(a, b) == pytest.approx(1.0)
+    assert not ncuts_ref.partitions_equal(a, np.array([0, 1, 5, 5, 9]))
