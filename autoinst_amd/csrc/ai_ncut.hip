@@ -380,7 +380,8 @@ __device__ __forceinline__ int sturm_lt(const double* __restrict__ a, const doub
 __global__ __launch_bounds__(64) void k_lz_norm_check(SegDev sd, const double2* __restrict__ pB, double* __restrict__ alpha_hist,
                                                       double* __restrict__ b_hist, double* __restrict__ g_hist, int mcap,
                                                       int m /* = j + 1; 0 right after init */, int check, double tol, int max_iter,
-                                                      int32_t* __restrict__ n_running) {
+                                                      int32_t* __restrict__ n_running, const int32_t* __restrict__ rowptr,
+                                                      unsigned long long* __restrict__ work /* [rows, nnz] of the SpMV launches */) {
   const int s = blockIdx.x;
   if (sd.mode[s] != 0 || sd.frozen[s]) return;
   const int lane = threadIdx.x;
@@ -406,16 +407,25 @@ __global__ __launch_bounds__(64) void k_lz_norm_check(SegDev sd, const double2* 
     sd.b[s] = bnew;
     sd.rb[s] = (bnew > 0.0) ? 1.0 / bnew : 0.0;
   }
+  const int ns = sd.start[s + 1] - sd.start[s];
+  const unsigned long long nnz_s = (unsigned long long)(rowptr[sd.start[s + 1]] - rowptr[sd.start[s]]);
   if (m == 0) {
-    if (lane == 0) atomicAdd(n_running, 1);
+    if (lane == 0) {
+      atomicAdd(n_running, 1);
+      atomicAdd(&work[0], (unsigned long long)ns);
+      atomicAdd(&work[1], nnz_s);
+    }
     return;
   }
-  const int ns = sd.start[s + 1] - sd.start[s];
   const int cap = min(ns - 1, max_iter);
   const bool breakdown = !(bnew > 1e-14);
   const bool last = (m >= cap) || (m >= mcap);
   if (!(check || breakdown || last)) {
-    if (lane == 0) atomicAdd(n_running, 1);
+    if (lane == 0) {
+      atomicAdd(n_running, 1);
+      atomicAdd(&work[0], (unsigned long long)ns);
+      atomicAdd(&work[1], nnz_s);
+    }
     return;
   }
   // ---- top eigenvalue of T_m
@@ -471,6 +481,8 @@ __global__ __launch_bounds__(64) void k_lz_norm_check(SegDev sd, const double2* 
       sd.m[s] = m;
     } else {
       atomicAdd(n_running, 1);
+      atomicAdd(&work[0], (unsigned long long)ns);
+      atomicAdd(&work[1], nnz_s);
     }
   }
 }
@@ -967,6 +979,9 @@ class Solver {
   const ai_csr* A;
   hipStream_t st;
   ai_ncut_opts opt{1e-10, 4000, 16, 0};
+  bool time_spmv = false;           // opts.reserved bit 0: HIP events around every SpMV launch
+  std::vector<hipEvent_t> evpool;   // 2 per launch of the current level
+  DevBuf<unsigned long long> work;  // [rows, nnz] processed by the SpMV kernel
   ai_ncut_stats stats{};
 
   // active set
@@ -1001,6 +1016,7 @@ class Solver {
   size_t slab_stride = 0;
   ~Solver() {
     for (double* p : slabs) (void)hipFree(p);
+    for (hipEvent_t e : evpool) (void)hipEventDestroy(e);
   }
 
   SegDev segdev() {
@@ -1044,6 +1060,8 @@ class Solver {
     AI_TRY(side.alloc(n));
     AI_TRY(bin.alloc(n));
     AI_TRY(n_running.alloc(1));
+    AI_TRY(work.alloc(2));
+    AI_HIP(hipMemsetAsync(work.p, 0, 2 * sizeof(unsigned long long), st));
     return AI_OK;
   }
 
@@ -1261,16 +1279,25 @@ class Solver {
     hipLaunchKernelGGL(k_lz_init, dim3(ntask), dim3(AI_BLOCK), 0, st, task_seg.p, task_lo.p, task_hi.p, s_mode.p, orig, u1.p, vec(0), pB.p);
     AI_KERNEL_CHECK();
     hipLaunchKernelGGL(k_lz_norm_check, dim3(S_), dim3(64), 0, st, sd, (const double2*)pB.p, alpha_hist.p, b_hist.p, g_hist.p, mcap, 0, 0,
-                       opt.tol, opt.max_iter, n_running.p);
+                       opt.tol, opt.max_iter, n_running.p, rowptr, work.p);
     AI_KERNEL_CHECK();
     const bool dense_checks = (min_n <= 512);
     int next_check = dense_checks ? 1 : opt.check_every;
     int steps = 0;
     for (int j = 0; j < mcap; ++j) {
       AI_TRY(ensure_vec(j + 1));
+      if (time_spmv) {
+        while (evpool.size() < (size_t)2 * (j + 1)) {
+          hipEvent_t e;
+          AI_HIP(hipEventCreate(&e));
+          evpool.push_back(e);
+        }
+        AI_HIP(hipEventRecord(evpool[2 * j], st));
+      }
       hipLaunchKernelGGL(k_lz_spmv, dim3(ntask), dim3(AI_BLOCK), 0, st, task_seg.p, task_lo.p, task_hi.p, ntask, s_mode.p, s_frozen.p,
                          s_g.p, s_rb.p, rowptr, col, wm.p, sinv2.p, u1.p, (const double*)vec(j), Y.p, pA.p);
       AI_KERNEL_CHECK();
+      if (time_spmv) AI_HIP(hipEventRecord(evpool[2 * j + 1], st));
       hipLaunchKernelGGL(k_lz_alpha, dim3(S_), dim3(AI_BLOCK), 0, st, sd, (const double*)pA.p, alpha_hist.p, mcap, j);
       AI_KERNEL_CHECK();
       hipLaunchKernelGGL(k_lz_update, dim3(ntask), dim3(AI_BLOCK), 0, st, task_seg.p, task_lo.p, task_hi.p, sd, u1.p, (const double*)Y.p,
@@ -1280,7 +1307,7 @@ class Solver {
       const bool check = (m >= next_check) || (m == mcap);
       AI_HIP(hipMemsetAsync(n_running.p, 0, sizeof(int32_t), st));
       hipLaunchKernelGGL(k_lz_norm_check, dim3(S_), dim3(64), 0, st, sd, (const double2*)pB.p, alpha_hist.p, b_hist.p, g_hist.p, mcap, m,
-                         check ? 1 : 0, opt.tol, opt.max_iter, n_running.p);
+                         check ? 1 : 0, opt.tol, opt.max_iter, n_running.p, rowptr, work.p);
       AI_KERNEL_CHECK();
       ++steps;
       if (check || dense_checks) {
@@ -1292,7 +1319,15 @@ class Solver {
       }
     }
     stats.lanczos_steps += steps;
-    stats.spmv_rows += (int64_t)steps * lz_rows;  // upper bound: frozen segments drop out early
+    (void)lz_rows;
+    if (time_spmv) {
+      AI_HIP(hipStreamSynchronize(st));
+      for (int j = 0; j < steps; ++j) {
+        float e = 0.f;
+        AI_HIP(hipEventElapsedTime(&e, evpool[2 * j], evpool[2 * j + 1]));
+        stats.ms_spmv += e;
+      }
+    }
     // ---- Ritz coefficients on the host (tiny), Ritz vectors on the device
     std::vector<int32_t> h_m(S_);
     std::vector<double> h_a((size_t)S_ * mcap), h_b((size_t)S_ * (mcap + 1)), h_g((size_t)S_ * (mcap + 1)), h_coef((size_t)S_ * mcap, 0.0),
@@ -1391,6 +1426,7 @@ static void fill_opts(Solver& S, const ai_ncut_opts* opts) {
   if (opts->tol > 0.0) S.opt.tol = opts->tol;
   if (opts->max_iter > 0) S.opt.max_iter = opts->max_iter;
   if (opts->check_every > 0) S.opt.check_every = opts->check_every;
+  S.time_spmv = (opts->reserved & 1) != 0;
 }
 
 extern "C" int ai_ncut(ai_ctx* ctx, const ai_csr* csr, int64_t num_points_orig, double T, double split_lim, const ai_ncut_opts* opts,
@@ -1514,6 +1550,13 @@ extern "C" int ai_ncut(ai_ctx* ctx, const ai_csr* csr, int64_t num_points_orig, 
   }
   *n_groups = g + 1;
   S.stats.n_groups = g + 1;
+  {
+    unsigned long long hw[2] = {0, 0};
+    AI_HIP(hipMemcpyAsync(hw, S.work.p, sizeof(hw), hipMemcpyDeviceToHost, st));
+    AI_HIP(hipStreamSynchronize(st));
+    S.stats.spmv_rows = (int64_t)hw[0];
+    S.stats.spmv_nnz = (int64_t)hw[1];
+  }
   S.stats.ms_total = now_ms() - t0;
   if (stats_out) *stats_out = S.stats;
   return AI_OK;

@@ -124,31 +124,58 @@ def _as_f64(a, cols=None, name="array"):
     return a
 
 
+def _is_device_tensor(a):
+    return a is not None and hasattr(a, "data_ptr") and bool(getattr(a, "is_cuda", False))
+
+
+def _dev_f64(a, cols, name):
+    """A torch tensor already resident in HBM: float64, contiguous, (n, cols)."""
+    import torch
+    if a.dtype != torch.float64 or not a.is_contiguous() or a.dim() != 2 or (cols is not None and a.shape[1] != cols):
+        raise ValueError(f"{name} on the device must be a contiguous float64 (n, {cols or 'F'}) tensor")
+    return a
+
+
 def build_affinity(points, tarl=None, dino=None, *, alpha=CONFIG["alpha"], theta=CONFIG["theta"],
                    gamma=CONFIG["gamma"], radius=PROXIMITY_THRESHOLD, ctx: Context | None = None) -> DeviceGraph:
     """Affinity graph of one chunk, left on the device (``ncuts_utils.py:60-67,112-167``).
 
     ``A_ij = 1[d_ij <= radius] * exp(-theta t_ij) * exp(-alpha d_ij) * exp(-gamma g_ij)`` with the
     reference's rules: a falsy weight drops its factor, all-zero TARL rows have t = 0, A_ii = 1.
+    Inputs are NumPy arrays (copied to the device by the call) or torch tensors that already
+    live on the context's GPU (used in place; PyTorch here is only the owner of the HBM buffer).
     """
     ctx = ctx or default_context()
-    pts = _as_f64(points, 3, "points")
-    n = pts.shape[0]
     if gamma and dino is None:
         raise ValueError("The length should be longer than 0!")  # ncuts_utils.py:126-127
     if theta and tarl is None:
         raise ValueError("theta != 0 needs TARL features")
-    t = _as_f64(tarl, None, "tarl") if theta else None
-    d = _as_f64(dino, None, "dino") if gamma else None
+    on_dev = _is_device_tensor(points)
+    if on_dev:
+        import torch
+        pts = _dev_f64(points, 3, "points")
+        t = _dev_f64(tarl, None, "tarl") if theta else None
+        d = _dev_f64(dino, None, "dino") if gamma else None
+        for f in (t, d):
+            if f is not None and not _is_device_tensor(f):
+                raise ValueError("points are on the device, so features must be too")
+        torch.cuda.current_stream(pts.device).synchronize()  # producers of the buffers have finished
+        ptr = lambda a: C.c_void_p(a.data_ptr()) if a is not None else None
+        mem = _ffi.AI_MEM_DEVICE
+    else:
+        pts = _as_f64(points, 3, "points")
+        t = _as_f64(tarl, None, "tarl") if theta else None
+        d = _as_f64(dino, None, "dino") if gamma else None
+        ptr = lambda a: a.ctypes.data if a is not None else None
+        mem = _ffi.AI_MEM_HOST
+    n = pts.shape[0]
     for f, nm in ((t, "tarl"), (d, "dino")):
         if f is not None and f.shape[0] != n:
             raise ValueError(f"{nm} has {f.shape[0]} rows for {n} points")
     h = C.c_void_p()
     st = _ffi.load().ai_affinity_build(
-        ctx._h, pts.ctypes.data, n,
-        t.ctypes.data if t is not None else None, t.shape[1] if t is not None else 0,
-        d.ctypes.data if d is not None else None, d.shape[1] if d is not None else 0,
-        float(alpha or 0.0), float(theta or 0.0), float(gamma or 0.0), float(radius), _ffi.AI_MEM_HOST, C.byref(h))
+        ctx._h, ptr(pts), n, ptr(t), t.shape[1] if t is not None else 0, ptr(d), d.shape[1] if d is not None else 0,
+        float(alpha or 0.0), float(theta or 0.0), float(gamma or 0.0), float(radius), mem, C.byref(h))
     _ffi.check(st, "ai_affinity_build")
     return DeviceGraph(ctx, h)
 
@@ -163,18 +190,18 @@ def get_affinity_matrix(points, tarl=None, dino=None, *, alpha=CONFIG["alpha"], 
         g.free()
 
 
-def _opts(tol, max_iter, check_every):
-    return _ffi.NcutOpts(float(tol or 0.0), int(max_iter or 0), int(check_every or 0), 0)
+def _opts(tol, max_iter, check_every, time_spmv=False):
+    return _ffi.NcutOpts(float(tol or 0.0), int(max_iter or 0), int(check_every or 0), 1 if time_spmv else 0)
 
 
 def ncuts_labels(graph: DeviceGraph, num_points_orig: int, T: float, split_lim: float = SPLIT_LIM, *,
-                 tol=None, max_iter=None, check_every=None):
+                 tol=None, max_iter=None, check_every=None, time_spmv=False):
     """Run the recursion on a device graph; returns (labels[int32 n], n_groups, stats dict)."""
     global _last_stats
     lab = np.empty(graph.n, dtype=np.int32)
     ng = C.c_int32()
     stats = _ffi.NcutStats()
-    o = _opts(tol, max_iter, check_every)
+    o = _opts(tol, max_iter, check_every, time_spmv)
     _ffi.check(_ffi.load().ai_ncut(graph.ctx._h, graph._h, int(num_points_orig), float(T), float(split_lim),
                                    C.byref(o), lab.ctypes.data, C.byref(ng), C.byref(stats)), "ai_ncut")
     _last_stats = stats.as_dict()

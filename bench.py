@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Benchmark of the NCuts hot path on MI355X (contract in the project brief, section (4)).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one chunk: affinity build (TARL + spatial) from
+inputs already resident in HBM, recursive normalized cut, labels back on the host, and (N > 1)
+the gather of the label arrays to rank 0.  Workload = BASELINE.json configs[1]: a 200 000-point
+chunk, alpha = 1, theta = 0.5 (96-d features), T = 0.03; synthetic surface chunk.
+Chunks are independent, so ranks process different chunks with no data-path collective
+("weak" scaling: one chunk per rank per step).
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the fused Lanczos SpMV,
+`k_lz_spmv`): algorithmic bytes of its launches / their summed duration, both from a profiled
+repeat of the same step with HIP events around every launch on the library's stream.
+`cpu_baseline` is the oracle (NumPy / SciPy restatement, scipy eigsh shift-invert as the
+reference) timed on this host on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_POINTS = 200_000
+CFG = dict(alpha=1.0, theta=0.5, gamma=0.0, T=0.03)
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def spmv_bytes(rows: int, nnz: int, launches: int) -> float:
+    """Algorithmic bytes of the fused SpMV launches.
+
+    Per stored entry: 4 B column index + 8 B scaled weight.  Per row: 4 B row pointer, and
+    8 B each for R_j (read once: the gathers re-use it from cache), sinv2, u1 and the y written.
+    """
+    return nnz * 12.0 + rows * (4.0 + 4 * 8.0) + launches * 4.0
+
+
+def cpu_baseline(seconds_budget: float = 30.0):
+    """Oracle on a bounded sample: one 20 000-point chunk of the same generator and config."""
+    from autoinst_amd import synth
+    from oracle import ncuts_ref
+    n = 20_000
+    ch = synth.synthetic_chunk(n, seed=0, tarl=True)
+    t0 = time.perf_counter()
+    groups = ncuts_ref.ncuts(ch["points"], ch["tarl"], alpha=CFG["alpha"], theta=CFG["theta"], gamma=CFG["gamma"],
+                             T=CFG["T"], fast=True)
+    dt = time.perf_counter() - t0
+    # linear scaling in points flatters the CPU (eigsh grows faster than N: BASELINE.md section 2)
+    return {
+        "value": (n / dt) / N_POINTS,
+        "unit": "chunks/sec",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"oracle/ncuts_ref.ncuts (cKDTree affinity + scipy eigsh sigma=1e-10 recursion) on one {n}-point "
+                  f"TARL+Spatial chunk: {dt:.1f} s, {len(groups)} groups; scaled linearly in points to a {N_POINTS}-point chunk",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from autoinst_amd import ncuts_api as api
+    from autoinst_amd import sharding, synth
+
+    ctx = api.Context(local_rank)
+    # one chunk per rank (different seeds = different chunks of the map), resident in HBM
+    ch = synth.synthetic_chunk(N_POINTS, seed=rank, tarl=True)
+    dev = torch.device("cuda", local_rank)
+    pts_d = torch.from_numpy(ch["points"]).to(dev)
+    tarl_d = torch.from_numpy(ch["tarl"]).to(dev)
+    torch.cuda.synchronize()
+
+    def step(profile=False):
+        g = api.build_affinity(pts_d, tarl_d, alpha=CFG["alpha"], theta=CFG["theta"], gamma=CFG["gamma"], ctx=ctx)
+        try:
+            lab, ng, st = api.ncuts_labels(g, N_POINTS, CFG["T"], time_spmv=profile)
+        finally:
+            nnz = g.nnz
+            g.free()
+        merged = sharding.gather_labels({rank: lab}, device=dev) if world > 1 else {rank: lab}
+        return lab, ng, st, nnz, merged
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    lab, ng, st, nnz, merged = last
+
+    # profiled repeat of the same step: HIP events around every SpMV launch (rank 0 reports)
+    _, _, stp, _, _ = step(profile=True)
+    barrier()
+
+    if rank == 0:
+        assert merged is not None and len(merged) == world and all(v.shape[0] == N_POINTS for v in merged.values())
+        launches = int(stp["lanczos_steps"])
+        b = spmv_bytes(int(stp["spmv_rows"]), int(stp["spmv_nnz"]), launches)
+        ach = b / (stp["ms_spmv"] * 1e-3) / 1e9 if stp["ms_spmv"] > 0 else 0.0
+        out = {
+            "metric": "chunks/sec (200k-pt TARL+Spatial NCuts chunk: affinity build + recursive normalized cut)",
+            "value": world * args.steps / elapsed,
+            "unit": "chunks/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: single 200k-point surface chunk, TARL(96-d)+Spatial affinities, "
+                                   "alpha=1 theta=0.5 T=0.03, one chunk per GPU per step",
+                       "n_points": N_POINTS, "nnz": int(nnz), "chunks_per_step": world, "parallelism": f"chunk-dp{world}"},
+            "eigensolve_ms": st["ms_eigen"],
+            "ncut_ms": st["ms_total"],
+            "sweep_ms": st["ms_sweep"],
+            "rebuild_ms": st["ms_rebuild"],
+            "levels": int(st["levels"]),
+            "lanczos_solves": int(st["lanczos_solves"]),
+            "null_solves": int(st["null_solves"]),
+            "lanczos_steps": int(st["lanczos_steps"]),
+            "groups": int(ng),
+            "unconverged": int(st["unconverged"]),
+            "roofline": {
+                "kernel": "k_lz_spmv",
+                "bound": "hbm",
+                "achieved": ach,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBPS,
+                "traffic": None,
+                "launches": launches,
+                "avg_launch_us": 1e3 * stp["ms_spmv"] / max(launches, 1),
+                "bytes_per_launch_avg": b / max(launches, 1),
+            },
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -86,7 +86,7 @@ typedef struct {
   double tol;           /* Ritz residual |beta_m s_m| at which a Lanczos solve stops (default 1e-10) */
   int32_t max_iter;     /* Lanczos step cap per solve (default 4000) */
   int32_t check_every;  /* steps between convergence checks on large segments (default 16) */
-  int32_t reserved;
+  int32_t reserved;     /* bit 0: time every SpMV launch with HIP events (fills ms_spmv; for bench.py) */
 } ai_ncut_opts;
 
 typedef struct {
@@ -94,13 +94,13 @@ typedef struct {
   int64_t lanczos_solves;  /* connected segments solved by Lanczos */
   int64_t null_solves;     /* disconnected segments given a null-space vector */
   int64_t lanczos_steps;   /* sum over levels of lock-step Lanczos steps (= fused SpMV launches) */
-  int64_t spmv_rows;       /* rows processed by the SpMV kernel, summed over launches */
+  int64_t spmv_rows;       /* rows processed by the SpMV kernel, summed over launches (exact, counted on device) */
   int64_t spmv_nnz;        /* stored entries processed by the SpMV kernel, summed over launches */
   int64_t unconverged;     /* solves that hit max_iter before tol */
   int64_t n_groups;
   double ms_total;         /* host wall time of the call */
   double ms_eigen;         /* device time in the Lanczos / Ritz phase (HIP events) */
-  double ms_spmv;          /* device time in the fused SpMV kernel alone (HIP events) */
+  double ms_spmv;          /* device time in the fused SpMV kernel alone (HIP events; only with reserved bit 0) */
   double ms_sweep;         /* device time in min/max + bin + sweep */
   double ms_rebuild;       /* device time in CC + partition + CSR rebuild */
   double max_resid;        /* largest accepted Ritz residual */
