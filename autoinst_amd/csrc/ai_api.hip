@@ -40,6 +40,8 @@ extern "C" int ai_ctx_create(int device, ai_ctx** out) {
   c->num_cu = prop.multiProcessorCount;
   AI_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   for (int i = 0; i < 8; ++i) AI_HIP(hipEventCreate(&c->ev[i]));
+  for (int i = 0; i < AI_CHECK_DEPTH; ++i) AI_HIP(hipEventCreateWithFlags(&c->chk_ev[i], hipEventDisableTiming));
+  AI_HIP(hipHostMalloc((void**)&c->pinned, AI_PINNED_INTS * sizeof(int32_t), hipHostMallocDefault));
   *out = c;
   return AI_OK;
 }
@@ -49,6 +51,8 @@ extern "C" int ai_ctx_destroy(ai_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (int i = 0; i < 8; ++i) (void)hipEventDestroy(ctx->ev[i]);
+  for (int i = 0; i < AI_CHECK_DEPTH; ++i) (void)hipEventDestroy(ctx->chk_ev[i]);
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return AI_OK;

@@ -29,11 +29,15 @@ void ai_set_error(const char* fmt, ...);
 #define AI_KERNEL_CHECK() AI_HIP(hipGetLastError())
 
 // ----------------------------------------------------------------------------- handles
+#define AI_PINNED_INTS 4096
+#define AI_CHECK_DEPTH 16
 struct ai_ctx {
   int device;
   hipStream_t stream;
   hipEvent_t ev[8];
   int num_cu;
+  int32_t* pinned;          // AI_PINNED_INTS host-pinned ints: results of in-flight convergence checks
+  hipEvent_t chk_ev[AI_CHECK_DEPTH];  // one event per in-flight check
 };
 
 struct ai_csr {

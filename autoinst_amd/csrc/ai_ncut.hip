@@ -14,54 +14,50 @@
 //   * a CONNECTED segment is solved by Lanczos on M = D^-1/2 W D^-1/2 = I - L without
 //     re-orthogonalisation, every Lanczos vector kept in HBM, the known top eigenvector
 //     u1 = D^1/2 1 / sqrt(vol) projected out of each new vector; the top Ritz pair of T_m is the
-//     pair of L's 2nd-smallest eigenvalue.  All segments step together: one fused SpMV launch
-//     per step for the whole frontier, per-segment alpha / beta by two-stage fixed-order sums
-//     (no float atomics: results are reproducible run to run).
+//     pair of L's 2nd-smallest eigenvalue.  All segments step together: two launches per step
+//     for the whole frontier (fused SpMV; fused alpha / beta / three-term update), per-segment
+//     sums by two-stage fixed-order reductions (no float atomics: reproducible run to run).
 // tests/gpu_model.py is the NumPy model of this algorithm.
 #include <math.h>
 #include <string.h>
 
 #include <algorithm>
 #include <chrono>
+#include <set>
 
 #include "ai_common.h"
 
-#define AI_TASK_ROWS 128  // rows per block ("task"); a task never straddles two segments
-#define AI_SLAB_VECS 32   // Lanczos vectors per HBM slab
-#define AI_SWEEP_VALS 40  // per-task sweep partials: cut[10], assocA[10], assocB[10], cntA[10]
+#define AI_FINE_ROWS 64      // rows per block in the 16-lanes-per-row kernels (4 rows in flight per lane group)
+#define AI_COARSE_ROWS 1024  // rows per block in the thread-per-row kernels
+#define AI_ROW_ILP (AI_FINE_ROWS / (AI_BLOCK / AI_LPR))
+#define AI_SLAB_VECS 32      // Lanczos vectors per HBM slab
+#define AI_SWEEP_VALS 40     // per-task sweep partials: cut[10], assocA[10], assocB[10], cntA[10]
+#define AI_MAX_CHECKS 4096   // convergence checks per level (one counter slot each)
 
 namespace {
 
-// per-segment scalars that the kernels read (structure of arrays on the device)
-struct SegDev {
-  const int32_t* start;    // [S+1] first compact row of each segment
-  const int32_t* task0;    // [S+1] first task of each segment
-  int32_t* mode;           // [S] 0 = Lanczos, 1 = null-space vector, 2 = idle
-  int32_t* frozen;         // [S] Lanczos finished for this segment
-  int32_t* m;              // [S] size of T at freeze
-  double* g;               // [S] u1 . R_j
-  double* b;               // [S] norm of the projected R_j
-  double* rb;              // [S] 1 / b
-  double* gp;              // [S] previous step's g
-  double* rbp;             // [S] previous step's 1 / b
-  double* alpha;           // [S] alpha_j of the running step
-  double* theta;           // [S] top Ritz value at the last check
-  double* resid;           // [S] Ritz residual estimate at the last check
-  double* vol;             // [S] sum of degrees
-};
+// A task = one block's contiguous row range inside ONE segment: {lo, hi, segment, first task of its segment}.
+typedef int4 Task;
+// For coarse tasks: the segment's fine-task range [x, y) and coarse-task range [z, w).
+typedef int4 TaskRange;
+
+// fixed-order sum of part[t0..t1) by one block; every thread returns the same value
+__device__ __forceinline__ double ai_range_sum(const double* __restrict__ part, int t0, int t1, double* sm) {
+  double a = 0.0;
+  for (int t = t0 + threadIdx.x; t < t1; t += AI_BLOCK) a += part[t];
+  return ai_block_sum(a, sm);
+}
 
 // ----------------------------------------------------------------------------- degrees, scaling
 // deg_i = 1 + sum_j w_ij (W = w + I, normalized_cut.py:38,42); s_i = 1 / sqrt(deg_i) (:43)
-__global__ __launch_bounds__(AI_BLOCK) void k_degree(const int32_t* __restrict__ task_seg, const int32_t* __restrict__ task_lo,
-                                                     const int32_t* __restrict__ task_hi, const int32_t* __restrict__ rowptr,
+__global__ __launch_bounds__(AI_BLOCK) void k_degree(const Task* __restrict__ tasks, const int32_t* __restrict__ rowptr,
                                                      const double* __restrict__ wraw, double* __restrict__ deg,
                                                      double* __restrict__ sinv, double* __restrict__ pvol) {
   __shared__ double sm[AI_BLOCK / 64];
-  const int t = blockIdx.x;
-  const int lo = task_lo[t], hi = task_hi[t];
+  const Task tk = tasks[blockIdx.x];
   const int l = threadIdx.x & (AI_LPR - 1), r = threadIdx.x / AI_LPR;
   double acc = 0.0;
-  for (int row = lo + r; row < hi; row += AI_BLOCK / AI_LPR) {
+  for (int row = tk.x + r; row < tk.y; row += AI_BLOCK / AI_LPR) {
     const int p0 = rowptr[row], p1 = rowptr[row + 1];
     double s = 0.0;
     for (int p = p0 + l; p < p1; p += AI_LPR) s += wraw[p];
@@ -74,7 +70,7 @@ __global__ __launch_bounds__(AI_BLOCK) void k_degree(const int32_t* __restrict__
     }
   }
   const double tot = ai_block_sum(acc, sm);
-  if (threadIdx.x == 0) pvol[t] = tot;
+  if (threadIdx.x == 0) pvol[blockIdx.x] = tot;
 }
 
 // one block per segment: out[s] = sum of part[task0[s] .. task0[s+1]) in a fixed order
@@ -82,25 +78,21 @@ __global__ __launch_bounds__(AI_BLOCK) void k_seg_sum(const int32_t* __restrict_
                                                       double* __restrict__ out) {
   __shared__ double sm[AI_BLOCK / 64];
   const int s = blockIdx.x;
-  double a = 0.0;
-  for (int t = task0[s] + threadIdx.x; t < task0[s + 1]; t += AI_BLOCK) a += part[t];
-  const double tot = ai_block_sum(a, sm);
+  const double tot = ai_range_sum(part, task0[s], task0[s + 1], sm);
   if (threadIdx.x == 0) out[s] = tot;
 }
 
 // wm_ij = (s_i * w_ij) * s_j  (row scaling then column scaling, like D2 * (D - W) * D2, :47);
 // sinv2_i = s_i * s_i is the "+ I" term of W; u1_i = sqrt(deg_i / vol_seg)
-__global__ __launch_bounds__(AI_BLOCK) void k_scale(const int32_t* __restrict__ task_seg, const int32_t* __restrict__ task_lo,
-                                                    const int32_t* __restrict__ task_hi, const int32_t* __restrict__ rowptr,
+__global__ __launch_bounds__(AI_BLOCK) void k_scale(const Task* __restrict__ tasks, const int32_t* __restrict__ rowptr,
                                                     const int32_t* __restrict__ col, const double* __restrict__ wraw,
                                                     const double* __restrict__ deg, const double* __restrict__ sinv,
                                                     const double* __restrict__ vol, double* __restrict__ wm,
                                                     double* __restrict__ sinv2, double* __restrict__ u1) {
-  const int t = blockIdx.x;
-  const int lo = task_lo[t], hi = task_hi[t];
-  const double v = vol[task_seg[t]];
+  const Task tk = tasks[blockIdx.x];
+  const double v = vol[tk.z];
   const int l = threadIdx.x & (AI_LPR - 1), r = threadIdx.x / AI_LPR;
-  for (int row = lo + r; row < hi; row += AI_BLOCK / AI_LPR) {
+  for (int row = tk.x + r; row < tk.y; row += AI_BLOCK / AI_LPR) {
     const int p0 = rowptr[row], p1 = rowptr[row + 1];
     const double si = sinv[row];
     for (int p = p0 + l; p < p1; p += AI_LPR) wm[p] = (si * wraw[p]) * sinv[col[p]];
@@ -113,21 +105,22 @@ __global__ __launch_bounds__(AI_BLOCK) void k_scale(const int32_t* __restrict__ 
 
 // ----------------------------------------------------------------------------- connected components
 // Union-find with the smaller root as representative, so a component's label is its first row
-// and labels do not depend on scheduling.  parent[] is read and written with agent-scope
-// relaxed atomics: a CU's L1 is not refreshed by other CUs' stores inside one launch.
-__device__ __forceinline__ int32_t uf_load(int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// and labels do not depend on scheduling.  Plain loads may be stale inside a launch (a CU's L1 is
+// not refreshed by other CUs' stores); that is harmless here: every value ever stored in
+// parent[x] is an ancestor of x with a smaller-or-equal id, and hooking is decided by an
+// agent-scope compare-and-swap whose failure returns the up-to-date parent.
 __device__ __forceinline__ int32_t uf_find(int32_t* parent, int32_t x) {
-  int32_t p = uf_load(&parent[x]);
+  int32_t p = parent[x];
   while (p != x) {
-    const int32_t gp = uf_load(&parent[p]);
-    if (gp != p) __hip_atomic_store(&parent[x], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // path halving
+    const int32_t gp = parent[p];
+    if (gp != p) parent[x] = gp;  // path halving (benign race)
     x = p;
     p = gp;
   }
   return x;
 }
 __device__ __forceinline__ void uf_unite(int32_t* parent, int32_t a, int32_t b) {
-  for (int guard = 0; guard < (1 << 24); ++guard) {
+  for (int guard = 0; guard < (1 << 22); ++guard) {
     a = uf_find(parent, a);
     b = uf_find(parent, b);
     if (a == b) return;
@@ -136,62 +129,94 @@ __device__ __forceinline__ void uf_unite(int32_t* parent, int32_t a, int32_t b) 
       a = b;
       b = t;
     }
-    // hook the larger root under the smaller one
-    const int32_t old = atomicCAS(&parent[a], a, b);
+    const int32_t old = atomicCAS(&parent[a], a, b);  // hook the larger (apparent) root under the smaller id
     if (old == a) return;
-    a = old;
+    a = old;  // a was no longer a root: continue from its true parent
   }
 }
 
-__global__ __launch_bounds__(AI_BLOCK) void k_cc_init(int32_t* __restrict__ parent, int32_t n) {
-  const int i = blockIdx.x * AI_BLOCK + threadIdx.x;
-  if (i < n) parent[i] = i;
-}
-
-__global__ __launch_bounds__(AI_BLOCK) void k_cc_hook(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                                      int32_t n, int32_t* parent) {
-  const int64_t gid = (int64_t)blockIdx.x * AI_BLOCK + threadIdx.x;
-  const int32_t row = (int32_t)(gid / AI_LPR);
-  const int l = (int)(gid & (AI_LPR - 1));
-  if (row >= n) return;
-  const int p0 = rowptr[row], p1 = rowptr[row + 1];
-  for (int p = p0 + l; p < p1; p += AI_LPR) {
-    const int32_t c = col[p];
-    if (c < row) uf_unite(parent, row, c);
+// rows of segments that need a fresh labelling: parent = smallest neighbour id <= row (no cycles:
+// strictly decreasing chains); rows of the other segments keep the labels carried over the split
+__global__ __launch_bounds__(AI_BLOCK) void k_cc_init(const Task* __restrict__ tasks, const int32_t* __restrict__ need_cc,
+                                                      const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                      int32_t* __restrict__ parent) {
+  const Task tk = tasks[blockIdx.x];
+  if (!need_cc[tk.z]) return;
+  const int l = threadIdx.x & (AI_LPR - 1), r = threadIdx.x / AI_LPR;
+  for (int row = tk.x + r; row < tk.y; row += AI_BLOCK / AI_LPR) {
+    int32_t mn = row;
+    for (int p = rowptr[row] + l; p < rowptr[row + 1]; p += AI_LPR) mn = min(mn, col[p]);
+    mn = min(mn, __shfl_xor(mn, 8, 16));
+    mn = min(mn, __shfl_xor(mn, 4, 16));
+    mn = min(mn, __shfl_xor(mn, 2, 16));
+    mn = min(mn, __shfl_xor(mn, 1, 16));
+    if (l == 0) parent[row] = mn;
   }
 }
 
-__global__ __launch_bounds__(AI_BLOCK) void k_cc_compress(int32_t* parent, int32_t n) {
-  const int i = blockIdx.x * AI_BLOCK + threadIdx.x;
-  if (i >= n) return;
-  int32_t x = i;
-  // chains are static in this launch (no hooking), any value read is an ancestor
-  for (;;) {
-    const int32_t p = uf_load(&parent[x]);
-    if (p == x) break;
-    x = p;
+__global__ __launch_bounds__(AI_BLOCK) void k_cc_hook(const Task* __restrict__ tasks, const int32_t* __restrict__ need_cc,
+                                                      const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                      int32_t* parent) {
+  const Task tk = tasks[blockIdx.x];
+  if (!need_cc[tk.z]) return;
+  const int l = threadIdx.x & (AI_LPR - 1), r = threadIdx.x / AI_LPR;
+  for (int row = tk.x + r; row < tk.y; row += AI_BLOCK / AI_LPR) {
+    for (int p = rowptr[row] + l; p < rowptr[row + 1]; p += AI_LPR) {
+      const int32_t c = col[p];
+      if (c < row) uf_unite(parent, row, c);
+    }
   }
-  __hip_atomic_store(&parent[i], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(AI_BLOCK) void k_cc_compress(const Task* __restrict__ tasks, const int32_t* __restrict__ need_cc,
+                                                          int32_t* parent) {
+  const Task tk = tasks[blockIdx.x];
+  if (!need_cc[tk.z]) return;
+  for (int row = tk.x + threadIdx.x; row < tk.y; row += AI_BLOCK) {
+    int32_t x = row;
+    // chains are static in this launch (no hooking); stale values are still ancestors
+    for (;;) {
+      const int32_t p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (p == x) break;
+      x = p;
+    }
+    parent[row] = x;
+  }
 }
 
 // roots per segment (integer atomics: order independent)
-__global__ __launch_bounds__(AI_BLOCK) void k_cc_count(const int32_t* __restrict__ task_seg, const int32_t* __restrict__ task_lo,
-                                                       const int32_t* __restrict__ task_hi, const int32_t* __restrict__ parent,
+__global__ __launch_bounds__(AI_BLOCK) void k_cc_count(const Task* __restrict__ tasks, const int32_t* __restrict__ parent,
                                                        int32_t* __restrict__ ncomp) {
-  const int t = blockIdx.x;
+  const Task tk = tasks[blockIdx.x];
   int c = 0;
-  for (int row = task_lo[t] + threadIdx.x; row < task_hi[t]; row += AI_BLOCK) c += (parent[row] == row);
+  for (int row = tk.x + threadIdx.x; row < tk.y; row += AI_BLOCK) c += (parent[row] == row);
   for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-  if ((threadIdx.x & 63) == 0 && c) atomicAdd(&ncomp[task_seg[t]], c);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(&ncomp[tk.z], c);
 }
 
 // ----------------------------------------------------------------------------- null-space vector
-__global__ __launch_bounds__(AI_BLOCK) void k_null_rootcount(const int32_t* __restrict__ task_seg, const int32_t* __restrict__ task_lo,
-                                                             const int32_t* __restrict__ task_hi, const int32_t* __restrict__ mode,
+// rcnt[root] = rows of the component; runs of equal roots inside a wave are added once
+__global__ __launch_bounds__(AI_BLOCK) void k_null_rootcount(const Task* __restrict__ tasks, const int32_t* __restrict__ mode,
                                                              const int32_t* __restrict__ parent, int32_t* __restrict__ rcnt) {
-  const int t = blockIdx.x;
-  if (mode[task_seg[t]] != 1) return;
-  for (int row = task_lo[t] + threadIdx.x; row < task_hi[t]; row += AI_BLOCK) atomicAdd(&rcnt[parent[row]], 1);
+  const Task tk = tasks[blockIdx.x];
+  if (mode[tk.z] != 1) return;
+  const int lane = threadIdx.x & 63;
+  for (int base = tk.x; base < tk.y; base += AI_BLOCK) {
+    const int row = base + threadIdx.x;
+    const bool live = row < tk.y;
+    const int32_t r = live ? parent[row] : -1;
+    const int32_t prev = __shfl_up(r, 1, 64);
+    const bool head = live && (lane == 0 || prev != r);
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long lives = __ballot(live);
+    if (head) {
+      // run length = distance to the next head (or to the end of the live lanes)
+      const unsigned long long later = (lane == 63) ? 0ull : (heads >> (lane + 1));
+      const int nlive = __popcll(lives);
+      const int len = later ? (__ffsll((long long)later)) : (nlive - lane);
+      atomicAdd(&rcnt[r], len);
+    }
+  }
 }
 
 // rc[row] = size of the component if row is its root, else 0 (scanned to rank components by first row)
@@ -203,26 +228,25 @@ __global__ __launch_bounds__(AI_BLOCK) void k_null_rootvals(const int32_t* __res
 
 // side A = first component + every later component that still ends within the first half of
 // the segment's rows; partial volumes of both sides
-__global__ __launch_bounds__(AI_BLOCK) void k_null_side(const int32_t* __restrict__ task_seg, const int32_t* __restrict__ task_lo,
-                                                        const int32_t* __restrict__ task_hi, const int32_t* __restrict__ mode,
+__global__ __launch_bounds__(AI_BLOCK) void k_null_side(const Task* __restrict__ tasks, const int32_t* __restrict__ mode,
                                                         const int32_t* __restrict__ seg_start, const int32_t* __restrict__ parent,
                                                         const int32_t* __restrict__ rcnt, const int32_t* __restrict__ ex,
                                                         const double* __restrict__ deg, uint8_t* __restrict__ side,
                                                         double* __restrict__ pvolA, double* __restrict__ pvolB) {
   __shared__ double sm[AI_BLOCK / 64];
-  const int t = blockIdx.x;
-  const int s = task_seg[t];
+  const Task tk = tasks[blockIdx.x];
+  const int s = tk.z;
   if (mode[s] != 1) {
     if (threadIdx.x == 0) {
-      pvolA[t] = 0.0;
-      pvolB[t] = 0.0;
+      pvolA[blockIdx.x] = 0.0;
+      pvolB[blockIdx.x] = 0.0;
     }
     return;
   }
   const int s0 = seg_start[s], ns = seg_start[s + 1] - s0;
   const int exs = ex[s0];
   double va = 0.0, vb = 0.0;
-  for (int row = task_lo[t] + threadIdx.x; row < task_hi[t]; row += AI_BLOCK) {
+  for (int row = tk.x + threadIdx.x; row < tk.y; row += AI_BLOCK) {
     const int r = parent[row];
     const int cb = ex[r] - exs;
     const bool inA = (r == s0) || (2 * (int64_t)(cb + rcnt[r]) <= (int64_t)ns);
@@ -232,36 +256,37 @@ __global__ __launch_bounds__(AI_BLOCK) void k_null_side(const int32_t* __restric
   const double ta = ai_block_sum(va, sm);
   const double tb = ai_block_sum(vb, sm);
   if (threadIdx.x == 0) {
-    pvolA[t] = ta;
-    pvolB[t] = tb;
+    pvolA[blockIdx.x] = ta;
+    pvolB[blockIdx.x] = tb;
   }
 }
 
-__global__ __launch_bounds__(AI_BLOCK) void k_null_vec(const int32_t* __restrict__ task_seg, const int32_t* __restrict__ task_lo,
-                                                       const int32_t* __restrict__ task_hi, const int32_t* __restrict__ mode,
+__global__ __launch_bounds__(AI_BLOCK) void k_null_vec(const Task* __restrict__ tasks, const int32_t* __restrict__ mode,
                                                        const double* __restrict__ volA, const double* __restrict__ volB,
                                                        const double* __restrict__ deg, const uint8_t* __restrict__ side,
                                                        double* __restrict__ ev) {
-  const int t = blockIdx.x;
-  const int s = task_seg[t];
+  const Task tk = tasks[blockIdx.x];
+  const int s = tk.z;
   if (mode[s] != 1) return;
   const double ia = 1.0 / volA[s], ib = 1.0 / volB[s];
   const double rn = 1.0 / sqrt(ia + ib);  // ||D^1/2 (1_A/volA - 1_B/volB)||^2 = 1/volA + 1/volB
-  for (int row = task_lo[t] + threadIdx.x; row < task_hi[t]; row += AI_BLOCK)
-    ev[row] = sqrt(deg[row]) * (side[row] ? ia : -ib) * rn;
+  for (int row = tk.x + threadIdx.x; row < tk.y; row += AI_BLOCK) ev[row] = sqrt(deg[row]) * (side[row] ? ia : -ib) * rn;
 }
 
 // ----------------------------------------------------------------------------- Lanczos
+// Notation: R_j is the stored (unnormalised, unprojected) j-th vector, g_j = u1 . R_j,
+// b_j = ||R_j - g_j u1||, v_j = (R_j - g_j u1) / b_j the Lanczos vector.  T has diagonal
+// alpha_j = v_j . M v_j and off-diagonals b_1, b_2, ...
+
 // R_0 = hash(original id); partials of (R.R, u1.R)
-__global__ __launch_bounds__(AI_BLOCK) void k_lz_init(const int32_t* __restrict__ task_seg, const int32_t* __restrict__ task_lo,
-                                                      const int32_t* __restrict__ task_hi, const int32_t* __restrict__ mode,
+__global__ __launch_bounds__(AI_BLOCK) void k_lz_init(const Task* __restrict__ ctasks, const int32_t* __restrict__ cactive,
                                                       const int32_t* __restrict__ orig, const double* __restrict__ u1,
                                                       double* __restrict__ R0, double2* __restrict__ pB) {
   __shared__ double sm[AI_BLOCK / 64];
-  const int t = blockIdx.x;
-  if (mode[task_seg[t]] != 0) return;
+  if (!cactive[blockIdx.x]) return;
+  const Task tk = ctasks[blockIdx.x];
   double nn = 0.0, gg = 0.0;
-  for (int row = task_lo[t] + threadIdx.x; row < task_hi[t]; row += AI_BLOCK) {
+  for (int row = tk.x + threadIdx.x; row < tk.y; row += AI_BLOCK) {
     const double r = ai_hash_unit((uint32_t)orig[row]);
     R0[row] = r;
     nn = fma(r, r, nn);
@@ -269,95 +294,210 @@ __global__ __launch_bounds__(AI_BLOCK) void k_lz_init(const int32_t* __restrict_
   }
   const double tn = ai_block_sum(nn, sm);
   const double tg = ai_block_sum(gg, sm);
-  if (threadIdx.x == 0) pB[t] = make_double2(tn, tg);
+  if (threadIdx.x == 0) pB[blockIdx.x] = make_double2(tn, tg);
 }
 
-// THE hot kernel: y = M v_j for every running segment, v_j = (R_j - g u1) / b kept implicit:
-//   y_i = ((sum_k wm_ik R_j[k] + sinv2_i R_j[i]) - g u1_i) / b        (M u1 = u1)
-// 16 lanes per row, coalesced 64-B / 128-B runs of col / wm, gathers of R_j served by L2 / MALL;
-// per-task partial of alpha = v_j . y.
-__global__ __launch_bounds__(AI_BLOCK) void k_lz_spmv(const int32_t* __restrict__ task_seg, const int32_t* __restrict__ task_lo,
-                                                      const int32_t* __restrict__ task_hi, int ntask,
-                                                      const int32_t* __restrict__ mode, const int32_t* __restrict__ frozen,
-                                                      const double* __restrict__ seg_g, const double* __restrict__ seg_rb,
+// THE hot kernel: z = M R_j for every running segment,
+//   z_i = sum_k wm_ik R_j[k] + sinv2_i R_j[i]            (M = D^-1/2 (w + I) D^-1/2)
+// and the per-block partial of R_j . z.  No per-segment scalar is needed here: with v = (R - g u1)/b
+// and M u1 = u1,  alpha = v . M v = (R.z - g^2) / b^2  -- the update kernel finishes it.
+// 16 lanes per row (neighbour counts ~30-40) read 64-B / 128-B runs of col / wm; each lane group
+// keeps AI_ROW_ILP rows in flight so that the dependent chain rowptr -> col -> gather is overlapped
+// four deep; gathers of R_j are served by L2 / MALL.
+__global__ __launch_bounds__(AI_BLOCK) void k_lz_spmv(const Task* __restrict__ ftasks, const int32_t* __restrict__ factive, int ntask,
                                                       const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                       const double* __restrict__ wm, const double* __restrict__ sinv2,
-                                                      const double* __restrict__ u1, const double* __restrict__ Rj,
-                                                      double* __restrict__ Y, double* __restrict__ pA) {
+                                                      const double* __restrict__ Rj, double* __restrict__ Z,
+                                                      double* __restrict__ pA) {
   __shared__ double sm[AI_BLOCK / 64];
   const int t = ai_xcd_task(blockIdx.x, ntask);
-  const int s = task_seg[t];
-  if (mode[s] != 0 || frozen[s]) return;
-  const double g = seg_g[s], rb = seg_rb[s];
-  const int lo = task_lo[t], hi = task_hi[t];
+  const int act = factive[t];
+  const Task tk = ftasks[t];  // independent of the flag: both loads are in flight together
+  if (!act) return;
   const int l = threadIdx.x & (AI_LPR - 1), r = threadIdx.x / AI_LPR;
+  int p0[AI_ROW_ILP], p1[AI_ROW_ILP];
+  double sum[AI_ROW_ILP], ri[AI_ROW_ILP], s2[AI_ROW_ILP];
+  int len = 0;
+#pragma unroll
+  for (int u = 0; u < AI_ROW_ILP; ++u) {
+    const int row = tk.x + r + u * (AI_BLOCK / AI_LPR);
+    const bool ok = row < tk.y;
+    p0[u] = ok ? rowptr[row] : 0;
+    p1[u] = ok ? rowptr[row + 1] : 0;
+    // the diagonal "+ I" term needs only the row id: issue these loads before the dependent chain
+    ri[u] = (ok && l == 0) ? Rj[row] : 0.0;
+    s2[u] = (ok && l == 0) ? sinv2[row] : 0.0;
+    sum[u] = 0.0;
+  }
+#pragma unroll
+  for (int u = 0; u < AI_ROW_ILP; ++u) len = max(len, p1[u] - p0[u]);
+  for (int k = l; k < len; k += AI_LPR) {
+    int c[AI_ROW_ILP];
+    double w[AI_ROW_ILP];
+#pragma unroll
+    for (int u = 0; u < AI_ROW_ILP; ++u) {
+      const int p = p0[u] + k;
+      const bool ok = p < p1[u];
+      c[u] = ok ? col[p] : -1;
+      w[u] = ok ? wm[p] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < AI_ROW_ILP; ++u)
+      if (c[u] >= 0) sum[u] = fma(w[u], Rj[c[u]], sum[u]);
+  }
   double acc = 0.0;
-  for (int row = lo + r; row < hi; row += AI_BLOCK / AI_LPR) {
-    const int p0 = rowptr[row], p1 = rowptr[row + 1];
-    double sum = 0.0;
-    for (int p = p0 + l; p < p1; p += AI_LPR) sum = fma(wm[p], Rj[col[p]], sum);
-    sum = ai_group16_sum(sum);
-    if (l == 0) {
-      const double ri = Rj[row], ui = u1[row];
-      const double y = (fma(sinv2[row], ri, sum) - g * ui) * rb;
-      const double v = (ri - g * ui) * rb;
-      Y[row] = y;
-      acc = fma(v, y, acc);
+#pragma unroll
+  for (int u = 0; u < AI_ROW_ILP; ++u) {
+    const double sg = ai_group16_sum(sum[u]);
+    const int row = tk.x + r + u * (AI_BLOCK / AI_LPR);
+    if (l == 0 && row < tk.y) {
+      const double z = fma(s2[u], ri[u], sg);
+      Z[row] = z;
+      acc = fma(ri[u], z, acc);
     }
   }
   const double tot = ai_block_sum(acc, sm);
   if (threadIdx.x == 0) pA[t] = tot;
 }
 
-// alpha_j per running segment (one block per segment)
-__global__ __launch_bounds__(AI_BLOCK) void k_lz_alpha(SegDev sd, const double* __restrict__ pA, double* __restrict__ alpha_hist,
-                                                       int mcap, int j) {
-  __shared__ double sm[AI_BLOCK / 64];
-  const int s = blockIdx.x;
-  if (sd.mode[s] != 0 || sd.frozen[s]) return;
-  double a = 0.0;
-  for (int t = sd.task0[s] + threadIdx.x; t < sd.task0[s + 1]; t += AI_BLOCK) a += pA[t];
-  const double tot = ai_block_sum(a, sm);
-  if (threadIdx.x == 0) {
-    sd.alpha[s] = tot;
-    alpha_hist[(size_t)s * mcap + j] = tot;
+struct LzSeg {
+  int32_t* frozen;      // [S]
+  int32_t* m;           // [S] size of T at freeze
+  double* alpha_hist;   // [S][mcap]
+  double* b_hist;       // [S][mcap + 1]
+  double* g_hist;       // [S][mcap + 1]
+  int32_t* factive;     // fine-task activity flags
+  int32_t* cactive;     // coarse-task activity flags
+  int mcap;
+};
+
+__device__ __forceinline__ void lz_freeze(const LzSeg& L, int s, int m, TaskRange rg, int lane, int nlanes) {
+  if (lane == 0) {
+    L.frozen[s] = 1;
+    L.m[s] = m;
   }
+  for (int t = rg.x + lane; t < rg.y; t += nlanes) L.factive[t] = 0;
+  for (int t = rg.z + lane; t < rg.w; t += nlanes) L.cactive[t] = 0;
 }
 
-// R_{j+1} = y - alpha v_j - b v_{j-1}; partials of (R.R, u1.R) of the new vector
-__global__ __launch_bounds__(AI_BLOCK) void k_lz_update(const int32_t* __restrict__ task_seg, const int32_t* __restrict__ task_lo,
-                                                        const int32_t* __restrict__ task_hi, SegDev sd,
-                                                        const double* __restrict__ u1, const double* __restrict__ Y,
+// Step j, second launch: every block of a segment re-derives the segment's scalars from the
+// per-block partials in the same fixed order (so all blocks agree bit for bit):
+//   g_j, b_j from the partials of R_j;  alpha_j = (R_j . z - g_j^2) / b_j^2;
+// then  R_{j+1} = y - alpha_j v_j - b_j v_{j-1},  y = (z - g_j u1) / b_j,
+// and the partials (R.R, u1.R) of R_{j+1}.  The segment's first block records alpha_j, b_j, g_j.
+// A vanishing b_j (Krylov space exhausted) freezes the segment with T of size j.
+__global__ __launch_bounds__(AI_BLOCK) void k_lz_update(const Task* __restrict__ ctasks, const TaskRange* __restrict__ cranges,
+                                                        LzSeg L, int j, const double* __restrict__ pA,
+                                                        const double2* __restrict__ pBcur, double2* __restrict__ pBnext,
+                                                        const double* __restrict__ u1, const double* __restrict__ Z,
                                                         const double* __restrict__ Rj, const double* __restrict__ Rjm1,
-                                                        double* __restrict__ Rnext, double2* __restrict__ pB) {
-  __shared__ double sm[AI_BLOCK / 64];
-  const int t = blockIdx.x;
-  const int s = task_seg[t];
-  if (sd.mode[s] != 0 || sd.frozen[s]) return;
-  const double g = sd.g[s], rb = sd.rb[s], b = sd.b[s], gp = sd.gp[s], rbp = sd.rbp[s], al = sd.alpha[s];
-  double nn = 0.0, gg = 0.0;
-  for (int row = task_lo[t] + threadIdx.x; row < task_hi[t]; row += AI_BLOCK) {
-    const double ui = u1[row];
-    const double v = (Rj[row] - g * ui) * rb;
-    const double vm = (rbp != 0.0) ? (Rjm1[row] - gp * ui) * rbp : 0.0;
-    const double r = Y[row] - al * v - b * vm;
-    Rnext[row] = r;
-    nn = fma(r, r, nn);
-    gg = fma(ui, r, gg);
+                                                        double* __restrict__ Rnext) {
+  constexpr int RPT = AI_COARSE_ROWS / AI_BLOCK;  // rows per thread
+  __shared__ double sm3[3][AI_BLOCK / 64];
+  const int act = L.cactive[blockIdx.x];
+  const Task tk = ctasks[blockIdx.x];
+  const TaskRange rg = cranges[blockIdx.x];
+  if (!act) return;
+  const int s = tk.z;
+  // row data does not depend on the segment scalars: get it moving before the reductions
+  double zr[RPT], rr[RPT], rm[RPT], ur[RPT];
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    const int row = tk.x + threadIdx.x + q * AI_BLOCK;
+    const bool ok = row < tk.y;
+    zr[q] = ok ? Z[row] : 0.0;
+    rr[q] = ok ? Rj[row] : 0.0;
+    rm[q] = (ok && j > 0) ? Rjm1[row] : 0.0;
+    ur[q] = ok ? u1[row] : 0.0;
   }
-  const double tn = ai_block_sum(nn, sm);
-  const double tg = ai_block_sum(gg, sm);
-  if (threadIdx.x == 0) pB[t] = make_double2(tn, tg);
+  // previous step's scalars come from the history (written by an earlier launch)
+  double gp = 0.0, rbp = 0.0;
+  if (j > 0) {
+    gp = L.g_hist[(size_t)s * (L.mcap + 1) + j - 1];
+    rbp = 1.0 / L.b_hist[(size_t)s * (L.mcap + 1) + j - 1];
+  }
+  double a = 0.0, nn = 0.0, gg = 0.0;
+  for (int t = rg.x + threadIdx.x; t < rg.y; t += AI_BLOCK) a += pA[t];
+  for (int t = rg.z + threadIdx.x; t < rg.w; t += AI_BLOCK) {
+    const double2 v = pBcur[t];
+    nn += v.x;
+    gg += v.y;
+  }
+  // three block sums behind one pair of barriers; every thread adds the wave partials in the same order
+  a = ai_wave_sum(a);
+  nn = ai_wave_sum(nn);
+  gg = ai_wave_sum(gg);
+  const int w = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  if (ln == 0) {
+    sm3[0][w] = a;
+    sm3[1][w] = nn;
+    sm3[2][w] = gg;
+  }
+  __syncthreads();
+  a = 0.0;
+  nn = 0.0;
+  double g = 0.0;
+#pragma unroll
+  for (int i = 0; i < AI_BLOCK / 64; ++i) {
+    a += sm3[0][i];
+    nn += sm3[1][i];
+    g += sm3[2][i];
+  }
+  __syncthreads();
+  const double b = sqrt(fmax(nn - g * g, 0.0));  // ||R_j - g u1||, u1 has unit norm
+  if (j > 0 && !(b > 1e-14)) {
+    if (tk.w) lz_freeze(L, s, j, rg, threadIdx.x, AI_BLOCK);
+    return;
+  }
+  const double rb = 1.0 / b;
+  const double al = rb * rb * (a - g * g);
+  if (tk.w && threadIdx.x == 0) {
+    L.alpha_hist[(size_t)s * L.mcap + j] = al;
+    L.b_hist[(size_t)s * (L.mcap + 1) + j] = b;
+    L.g_hist[(size_t)s * (L.mcap + 1) + j] = g;
+  }
+  double n2 = 0.0, g2 = 0.0;
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    const int row = tk.x + threadIdx.x + q * AI_BLOCK;
+    if (row < tk.y) {
+      const double ui = ur[q];
+      const double y = (zr[q] - g * ui) * rb;
+      const double v = (rr[q] - g * ui) * rb;
+      const double vm = (j > 0) ? (rm[q] - gp * ui) * rbp : 0.0;
+      const double rnew = y - al * v - b * vm;
+      Rnext[row] = rnew;
+      n2 = fma(rnew, rnew, n2);
+      g2 = fma(ui, rnew, g2);
+    }
+  }
+  n2 = ai_wave_sum(n2);
+  g2 = ai_wave_sum(g2);
+  if (ln == 0) {
+    sm3[0][w] = n2;
+    sm3[1][w] = g2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tn = 0.0, tg = 0.0;
+#pragma unroll
+    for (int i = 0; i < AI_BLOCK / 64; ++i) {
+      tn += sm3[0][i];
+      tg += sm3[1][i];
+    }
+    pBnext[blockIdx.x] = make_double2(tn, tg);
+  }
 }
 
-// Number of eigenvalues of T_m (diag a[0..m), off-diag b[1..m)) that are < x, by sign changes of
-// the leading principal minors p_i = det(T_i - x I), rescaled by powers of two.
-__device__ __forceinline__ int sturm_lt(const double* __restrict__ a, const double* __restrict__ b, int m, double x) {
+// Number of eigenvalues of T_m (diag a[0..m), squared off-diagonals bb[1..m), both in LDS) that
+// are < x, by sign changes of the leading principal minors p_i = det(T_i - x I), rescaled by
+// powers of two.  The LDS reads do not depend on the recurrence, so they pipeline.
+__device__ __forceinline__ int sturm_lt(const double* a, const double* bb, int m, double x) {
   double pm = 1.0, p = a[0] - x;
   int cnt = (p < 0.0) ? 1 : 0;
+#pragma unroll 4
   for (int i = 1; i < m; ++i) {
-    const double bb = b[i];
-    double pn = (a[i] - x) * p - (bb * bb) * pm;
+    double pn = (a[i] - x) * p - bb[i] * pm;
     if (pn == 0.0) pn = (p > 0.0) ? -1e-300 : 1e-300;  // a zero takes the sign opposite to its predecessor
     cnt += ((pn < 0.0) != (p < 0.0)) ? 1 : 0;
     pm = p;
@@ -372,78 +512,67 @@ __device__ __forceinline__ int sturm_lt(const double* __restrict__ a, const doub
   return cnt;
 }
 
-// One wave per running segment, after step j (m = j + 1 rows of T):
-//   * b_{m}, g_{m} of the new vector from the task partials; shift the running scalars;
-//   * if `check`: top eigenvalue of T_m by 64-way multisection, |s_m| by the backward
-//     recurrence (the growing, hence stable, direction), residual = b_m |s_m|; freeze the segment
-//     when residual <= tol, when T has reached the segment's dimension, or on breakdown.
-__global__ __launch_bounds__(64) void k_lz_norm_check(SegDev sd, const double2* __restrict__ pB, double* __restrict__ alpha_hist,
-                                                      double* __restrict__ b_hist, double* __restrict__ g_hist, int mcap,
-                                                      int m /* = j + 1; 0 right after init */, int check, double tol, int max_iter,
-                                                      int32_t* __restrict__ n_running, const int32_t* __restrict__ rowptr,
-                                                      unsigned long long* __restrict__ work /* [rows, nnz] of the SpMV launches */) {
+// Convergence check after step j (m = j + 1 rows of T), one wave per running segment:
+// b_m from the partials of R_m; top eigenvalue of T_m by 64-way multisection; |s_m| by the
+// recurrence from the bottom row upwards (the growing, hence stable, direction);
+// residual = b_m |s_m|.  Freezes the segment when residual <= tol or T has reached the
+// segment's dimension / the step cap.  slot[0] counts the segments still running;
+// work[] accumulates rows and stored entries the SpMV kernel processed since the last check.
+__global__ __launch_bounds__(64) void k_lz_check(const int32_t* __restrict__ seg_start, const TaskRange* __restrict__ seg_range,
+                                                 const int32_t* __restrict__ mode, LzSeg L, const double2* __restrict__ pB, int m,
+                                                 double tol, int max_iter, int steps_since, const int32_t* __restrict__ rowptr,
+                                                 double* __restrict__ theta_out, double* __restrict__ resid_out,
+                                                 int32_t* __restrict__ slot, unsigned long long* __restrict__ work) {
   const int s = blockIdx.x;
-  if (sd.mode[s] != 0 || sd.frozen[s]) return;
+  if (mode[s] != 0) return;
+  if (L.frozen[s]) return;
   const int lane = threadIdx.x;
+  const int ns = seg_start[s + 1] - seg_start[s];
+  const TaskRange rg = seg_range[s];
+  if (lane == 0) {
+    atomicAdd(&work[0], (unsigned long long)ns * (unsigned long long)steps_since);
+    atomicAdd(&work[1], (unsigned long long)(rowptr[seg_start[s + 1]] - rowptr[seg_start[s]]) * (unsigned long long)steps_since);
+  }
   double nn = 0.0, gg = 0.0;
-  for (int t = sd.task0[s] + lane; t < sd.task0[s + 1]; t += 64) {
+  for (int t = rg.z + lane; t < rg.w; t += 64) {
     const double2 v = pB[t];
     nn += v.x;
     gg += v.y;
   }
   nn = ai_wave_sum(nn);
   gg = ai_wave_sum(gg);
-  const double nrm2 = nn - gg * gg;  // ||R - g u1||^2, u1 has unit norm
-  const double bnew = sqrt(fmax(nrm2, 0.0));
-  double* bh = b_hist + (size_t)s * (mcap + 1);
-  double* gh = g_hist + (size_t)s * (mcap + 1);
-  const double* ah = alpha_hist + (size_t)s * mcap;
-  if (lane == 0) {
-    bh[m] = bnew;
-    gh[m] = gg;
-    sd.gp[s] = sd.g[s];
-    sd.rbp[s] = (m == 0) ? 0.0 : sd.rb[s];
-    sd.g[s] = gg;
-    sd.b[s] = bnew;
-    sd.rb[s] = (bnew > 0.0) ? 1.0 / bnew : 0.0;
+  const double bnew = sqrt(fmax(nn - gg * gg, 0.0));
+  const double* bh = L.b_hist + (size_t)s * (L.mcap + 1);
+  const double* ah = L.alpha_hist + (size_t)s * L.mcap;
+  // T_m into LDS: a[0..m), b^2[0..m) (b^2[0] unused)
+  extern __shared__ double lds[];
+  double* la = lds;
+  double* lbb = lds + m;
+  for (int i = lane; i < m; i += 64) {
+    la[i] = ah[i];
+    const double bi = (i > 0) ? bh[i] : 0.0;
+    lbb[i] = bi * bi;
   }
-  const int ns = sd.start[s + 1] - sd.start[s];
-  const unsigned long long nnz_s = (unsigned long long)(rowptr[sd.start[s + 1]] - rowptr[sd.start[s]]);
-  if (m == 0) {
-    if (lane == 0) {
-      atomicAdd(n_running, 1);
-      atomicAdd(&work[0], (unsigned long long)ns);
-      atomicAdd(&work[1], nnz_s);
-    }
-    return;
-  }
-  const int cap = min(ns - 1, max_iter);
-  const bool breakdown = !(bnew > 1e-14);
-  const bool last = (m >= cap) || (m >= mcap);
-  if (!(check || breakdown || last)) {
-    if (lane == 0) {
-      atomicAdd(n_running, 1);
-      atomicAdd(&work[0], (unsigned long long)ns);
-      atomicAdd(&work[1], nnz_s);
-    }
-    return;
-  }
-  // ---- top eigenvalue of T_m
+  __syncthreads();
+  const int cap = min(min(ns - 1, max_iter), L.mcap);
+  const bool last = (m >= cap) || !(bnew > 1e-14);
+  // ---- top eigenvalue of T_m: lambda_max >= max diagonal, <= Gershgorin bound
   double lo = -1e300, hi = -1e300;
   for (int i = lane; i < m; i += 64) {
     const double bl = (i > 0) ? bh[i] : 0.0, br = (i + 1 < m) ? bh[i + 1] : 0.0;
-    lo = fmax(lo, ah[i]);
-    hi = fmax(hi, ah[i] + fabs(bl) + fabs(br));
+    lo = fmax(lo, la[i]);
+    hi = fmax(hi, la[i] + fabs(bl) + fabs(br));
   }
   for (int o = 32; o > 0; o >>= 1) {
     lo = fmax(lo, __shfl_xor(lo, o, 64));
     hi = fmax(hi, __shfl_xor(hi, o, 64));
   }
-  // lambda_max >= max diagonal; widen both ends a little so that count(lo) < m <= count(hi)
+  lo -= 1e-14 * fmax(fabs(lo), 1.0);
+  hi += 1e-14 * fmax(fabs(hi), 1.0);
   for (int round = 0; round < 12; ++round) {
     const double w = (hi - lo) * (1.0 / 65.0);
     const double x = lo + (lane + 1) * w;
-    const int c = sturm_lt(ah, bh, m, x);
+    const int c = sturm_lt(la, lbb, m, x);
     const unsigned long long above = __ballot(c == m);  // lanes whose x exceeds every eigenvalue
     if (above == 0ull) {
       lo = lo + 64.0 * w;
@@ -455,53 +584,47 @@ __global__ __launch_bounds__(64) void k_lz_norm_check(SegDev sd, const double2* 
     if (hi - lo <= 4.4e-16 * fmax(fabs(hi), 1e-300)) break;
   }
   const double theta = 0.5 * (lo + hi);
-  // ---- |s_m| / ||s|| by the recurrence from the bottom row upwards (s_m = 1)
+  // ---- |s_m| / ||s||: s_m = 1 at the start; `scale` follows the rescalings
+  double sk1 = 0.0, sk = 1.0, sumsq = 1.0, scale = 1.0;  // s_{k+1}, s_k (every lane computes the same)
+  for (int k = m - 1; k >= 1; --k) {
+    const double bu = (k + 1 < m) ? bh[k + 1] : 0.0;
+    const double sm1 = ((theta - la[k]) * sk - bu * sk1) / bh[k];
+    sk1 = sk;
+    sk = sm1;
+    sumsq += sk * sk;
+    if (sumsq > 1e200) {  // only ratios matter
+      sk *= 1e-100;
+      sk1 *= 1e-100;
+      sumsq *= 1e-200;
+      scale *= 1e-100;
+    }
+  }
+  const double resid = bnew * scale / sqrt(sumsq);
   if (lane == 0) {
-    // s_m = 1 at the start; `scale` follows the rescalings so that |s_m| = scale at the end
-    double sk1 = 0.0, sk = 1.0, sumsq = 1.0, scale = 1.0;  // s_{k+1}, s_k
-    for (int k = m - 1; k >= 1; --k) {
-      const double bu = (k + 1 < m) ? bh[k + 1] : 0.0;
-      const double sm1 = ((theta - ah[k]) * sk - bu * sk1) / bh[k];
-      sk1 = sk;
-      sk = sm1;
-      sumsq += sk * sk;
-      if (sumsq > 1e200) {  // only ratios matter
-        sk *= 1e-100;
-        sk1 *= 1e-100;
-        sumsq *= 1e-200;
-        scale *= 1e-100;
-      }
-    }
-    const double resid = bnew * scale / sqrt(sumsq);
-    const bool conv = (resid <= tol);
-    sd.theta[s] = theta;
-    sd.resid[s] = resid;
-    if (conv || breakdown || last) {
-      sd.frozen[s] = 1;
-      sd.m[s] = m;
-    } else {
-      atomicAdd(n_running, 1);
-      atomicAdd(&work[0], (unsigned long long)ns);
-      atomicAdd(&work[1], nnz_s);
-    }
+    theta_out[s] = theta;
+    resid_out[s] = resid;
+  }
+  if (resid <= tol || last) {
+    lz_freeze(L, s, m, rg, lane, 64);
+  } else if (lane == 0) {
+    atomicAdd(slot, 1);
   }
 }
 
-// ev = sum_j coef_j R_j + cu u1 for the rows of frozen Lanczos segments (one slab of vectors per launch)
-__global__ __launch_bounds__(AI_BLOCK) void k_ritz(const int32_t* __restrict__ task_seg, const int32_t* __restrict__ task_lo,
-                                                   const int32_t* __restrict__ task_hi, const int32_t* __restrict__ mode,
+// ev = sum_j coef_j R_j + cu u1 for the rows of Lanczos segments (one slab of vectors per launch)
+__global__ __launch_bounds__(AI_BLOCK) void k_ritz(const Task* __restrict__ ctasks, const int32_t* __restrict__ mode,
                                                    const int32_t* __restrict__ seg_m, const double* __restrict__ coef, int mcap,
                                                    const double* __restrict__ cu, const double* __restrict__ u1,
                                                    const double* __restrict__ slab, size_t stride, int j0, int nvec, int first,
                                                    double* __restrict__ ev) {
-  const int t = blockIdx.x;
-  const int s = task_seg[t];
+  const Task tk = ctasks[blockIdx.x];
+  const int s = tk.z;
   if (mode[s] != 0) return;
   const int m = seg_m[s];
   const int jn = min(nvec, m - j0);
   if (jn <= 0 && !first) return;
   const double* cs = coef + (size_t)s * mcap + j0;
-  for (int row = task_lo[t] + threadIdx.x; row < task_hi[t]; row += AI_BLOCK) {
+  for (int row = tk.x + threadIdx.x; row < tk.y; row += AI_BLOCK) {
     double acc = first ? cu[s] * u1[row] : ev[row];
     for (int j = 0; j < jn; ++j) acc = fma(cs[j], slab[(size_t)j * stride + row], acc);
     ev[row] = acc;
@@ -515,91 +638,68 @@ struct MinMaxPart {
   int32_t amax_neg;  // that entry is negative
 };
 
-__global__ __launch_bounds__(AI_BLOCK) void k_minmax(const int32_t* __restrict__ task_seg, const int32_t* __restrict__ task_lo,
-                                                     const int32_t* __restrict__ task_hi, const int32_t* __restrict__ mode,
-                                                     const double* __restrict__ ev, const int32_t* __restrict__ orig,
-                                                     MinMaxPart* __restrict__ part) {
+__device__ __forceinline__ void mm_merge(MinMaxPart& r, const MinMaxPart& q) {
+  r.mn = fmin(r.mn, q.mn);
+  r.mx = fmax(r.mx, q.mx);
+  r.sumsq += q.sumsq;
+  if (q.amax > r.amax || (q.amax == r.amax && q.amax_id < r.amax_id)) {
+    r.amax = q.amax;
+    r.amax_id = q.amax_id;
+    r.amax_neg = q.amax_neg;
+  }
+}
+
+__global__ __launch_bounds__(AI_BLOCK) void k_minmax(const Task* __restrict__ ctasks, const double* __restrict__ ev,
+                                                     const int32_t* __restrict__ orig, MinMaxPart* __restrict__ part) {
   __shared__ MinMaxPart sm[AI_BLOCK / 64];
-  const int t = blockIdx.x;
-  if (mode[task_seg[t]] == 2) return;
-  double mn = 1e300, mx = -1e300, ss = 0.0, am = -1.0;
-  int32_t aid = 0x7fffffff, aneg = 0;
-  for (int row = task_lo[t] + threadIdx.x; row < task_hi[t]; row += AI_BLOCK) {
+  const Task tk = ctasks[blockIdx.x];
+  MinMaxPart r;
+  r.mn = 1e300;
+  r.mx = -1e300;
+  r.sumsq = 0.0;
+  r.amax = -1.0;
+  r.amax_id = 0x7fffffff;
+  r.amax_neg = 0;
+  for (int row = tk.x + threadIdx.x; row < tk.y; row += AI_BLOCK) {
     const double e = ev[row];
-    const double a = fabs(e);
-    const int32_t id = orig[row];
-    mn = fmin(mn, e);
-    mx = fmax(mx, e);
-    ss = fma(e, e, ss);
-    if (a > am || (a == am && id < aid)) {
-      am = a;
-      aid = id;
-      aneg = e < 0.0;
-    }
+    MinMaxPart q;
+    q.mn = e;
+    q.mx = e;
+    q.sumsq = e * e;
+    q.amax = fabs(e);
+    q.amax_id = orig[row];
+    q.amax_neg = e < 0.0;
+    mm_merge(r, q);
   }
   for (int o = 32; o > 0; o >>= 1) {
-    mn = fmin(mn, __shfl_xor(mn, o, 64));
-    mx = fmax(mx, __shfl_xor(mx, o, 64));
-    ss += __shfl_xor(ss, o, 64);
-    const double oa = __shfl_xor(am, o, 64);
-    const int32_t oi = __shfl_xor(aid, o, 64), on = __shfl_xor(aneg, o, 64);
-    if (oa > am || (oa == am && oi < aid)) {
-      am = oa;
-      aid = oi;
-      aneg = on;
-    }
+    MinMaxPart q;
+    q.mn = __shfl_xor(r.mn, o, 64);
+    q.mx = __shfl_xor(r.mx, o, 64);
+    q.sumsq = __shfl_xor(r.sumsq, o, 64);
+    q.amax = __shfl_xor(r.amax, o, 64);
+    q.amax_id = __shfl_xor(r.amax_id, o, 64);
+    q.amax_neg = __shfl_xor(r.amax_neg, o, 64);
+    mm_merge(r, q);
   }
   const int w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) {
-    sm[w].mn = mn;
-    sm[w].mx = mx;
-    sm[w].sumsq = ss;
-    sm[w].amax = am;
-    sm[w].amax_id = aid;
-    sm[w].amax_neg = aneg;
-  }
+  if ((threadIdx.x & 63) == 0) sm[w] = r;
   __syncthreads();
   if (threadIdx.x == 0) {
-    MinMaxPart r = sm[0];
-    for (int i = 1; i < AI_BLOCK / 64; ++i) {
-      r.mn = fmin(r.mn, sm[i].mn);
-      r.mx = fmax(r.mx, sm[i].mx);
-      r.sumsq += sm[i].sumsq;
-      if (sm[i].amax > r.amax || (sm[i].amax == r.amax && sm[i].amax_id < r.amax_id)) {
-        r.amax = sm[i].amax;
-        r.amax_id = sm[i].amax_id;
-        r.amax_neg = sm[i].amax_neg;
-      }
-    }
-    part[t] = r;
+    MinMaxPart t = sm[0];
+    for (int i = 1; i < AI_BLOCK / 64; ++i) mm_merge(t, sm[i]);
+    part[blockIdx.x] = t;
   }
 }
 
 // Per segment: unit norm + sign convention folded into one scale; np.allclose(mn, mx) test
 // (normalized_cut.py:22); thresholds t_k = k * step + mn, step = (mx - mn) / 10, exactly as
 // np.linspace(mn, mx, 10, endpoint=False) computes them (:28).
-__global__ void k_minmax_final(const int32_t* __restrict__ task0, const int32_t* __restrict__ mode,
-                               const MinMaxPart* __restrict__ part, int S, int raw, double* __restrict__ scale,
-                               int32_t* __restrict__ nosplit, double* __restrict__ thr) {
+__global__ void k_minmax_final(const int32_t* __restrict__ ctask0, const MinMaxPart* __restrict__ part, int S, int raw,
+                               double* __restrict__ scale, int32_t* __restrict__ nosplit, double* __restrict__ thr) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= S) return;
-  if (mode[s] == 2) {
-    nosplit[s] = 1;
-    scale[s] = 1.0;
-    return;
-  }
-  MinMaxPart r = part[task0[s]];
-  for (int t = task0[s] + 1; t < task0[s + 1]; ++t) {
-    const MinMaxPart q = part[t];
-    r.mn = fmin(r.mn, q.mn);
-    r.mx = fmax(r.mx, q.mx);
-    r.sumsq += q.sumsq;
-    if (q.amax > r.amax || (q.amax == r.amax && q.amax_id < r.amax_id)) {
-      r.amax = q.amax;
-      r.amax_id = q.amax_id;
-      r.amax_neg = q.amax_neg;
-    }
-  }
+  MinMaxPart r = part[ctask0[s]];
+  for (int t = ctask0[s] + 1; t < ctask0[s + 1]; ++t) mm_merge(r, part[t]);
   double sc = 1.0;
   if (!raw) {
     const double nrm = sqrt(r.sumsq);
@@ -615,17 +715,16 @@ __global__ void k_minmax_final(const int32_t* __restrict__ task0, const int32_t*
 }
 
 // bin_i = number of thresholds strictly below ev_i: mask_k(i) = (ev_i > t_k) = (k < bin_i)
-__global__ __launch_bounds__(AI_BLOCK) void k_bin(const int32_t* __restrict__ task_seg, const int32_t* __restrict__ task_lo,
-                                                  const int32_t* __restrict__ task_hi, const double* __restrict__ scale,
+__global__ __launch_bounds__(AI_BLOCK) void k_bin(const Task* __restrict__ ctasks, const double* __restrict__ scale,
                                                   const double* __restrict__ thr, const double* __restrict__ ev,
                                                   uint8_t* __restrict__ bin) {
-  const int t = blockIdx.x;
-  const int s = task_seg[t];
+  const Task tk = ctasks[blockIdx.x];
+  const int s = tk.z;
   const double sc = scale[s];
   double th[AI_NUM_CUTS];
 #pragma unroll
   for (int k = 0; k < AI_NUM_CUTS; ++k) th[k] = thr[s * AI_NUM_CUTS + k];
-  for (int row = task_lo[t] + threadIdx.x; row < task_hi[t]; row += AI_BLOCK) {
+  for (int row = tk.x + threadIdx.x; row < tk.y; row += AI_BLOCK) {
     const double e = ev[row] * sc;
     int b = 0;
 #pragma unroll
@@ -638,19 +737,18 @@ __global__ __launch_bounds__(AI_BLOCK) void k_bin(const int32_t* __restrict__ ta
 //   cut_k    = sum over stored (i, j) with i in A_k, j in B_k of w_ij   (= (sum W - W_AA - W_BB) / 2)
 //   assocA_k = sum_{i in A_k} deg_i, assocB_k = sum_{i in B_k} deg_i   (deg of W = w + I)
 // An entry (i, j) with bin_j < bin_i is cut for every k in [bin_j, bin_i).
-__global__ __launch_bounds__(AI_BLOCK) void k_sweep(const int32_t* __restrict__ task_seg, const int32_t* __restrict__ task_lo,
-                                                    const int32_t* __restrict__ task_hi, const int32_t* __restrict__ nosplit,
+__global__ __launch_bounds__(AI_BLOCK) void k_sweep(const Task* __restrict__ ftasks, const int32_t* __restrict__ nosplit,
                                                     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                     const double* __restrict__ wraw, const double* __restrict__ deg,
                                                     const uint8_t* __restrict__ bin, double* __restrict__ part) {
   __shared__ double sm[AI_BLOCK / 64];
-  const int t = blockIdx.x;
-  if (nosplit[task_seg[t]]) return;
+  const Task tk = ftasks[blockIdx.x];
+  if (nosplit[tk.z]) return;
   const int l = threadIdx.x & (AI_LPR - 1), r = threadIdx.x / AI_LPR;
   double cut[AI_NUM_CUTS], aa[AI_NUM_CUTS], ab[AI_NUM_CUTS], ca[AI_NUM_CUTS];
 #pragma unroll
   for (int k = 0; k < AI_NUM_CUTS; ++k) cut[k] = aa[k] = ab[k] = ca[k] = 0.0;
-  for (int row = task_lo[t] + r; row < task_hi[t]; row += AI_BLOCK / AI_LPR) {
+  for (int row = tk.x + r; row < tk.y; row += AI_BLOCK / AI_LPR) {
     const int bi = bin[row];
     const int p0 = rowptr[row], p1 = rowptr[row + 1];
     for (int p = p0 + l; p < p1; p += AI_LPR) {
@@ -670,7 +768,7 @@ __global__ __launch_bounds__(AI_BLOCK) void k_sweep(const int32_t* __restrict__ 
       }
     }
   }
-  double* out = part + (size_t)t * AI_SWEEP_VALS;
+  double* out = part + (size_t)blockIdx.x * AI_SWEEP_VALS;
 #pragma unroll
   for (int k = 0; k < AI_NUM_CUTS; ++k) {
     const double c = ai_block_sum(cut[k], sm);
@@ -687,47 +785,51 @@ __global__ __launch_bounds__(AI_BLOCK) void k_sweep(const int32_t* __restrict__ 
 }
 
 // Per segment: ncut_k = cut_k / assocA_k + cut_k / assocB_k; first strictly smaller cost wins
-// (normalized_cut.py:29-32); split iff mcut < T (:56).
-__global__ __launch_bounds__(64) void k_sweep_final(const int32_t* __restrict__ task0, const int32_t* __restrict__ nosplit,
-                                                    const double* __restrict__ part, double T, double* __restrict__ costs,
-                                                    int32_t* __restrict__ kstar, int32_t* __restrict__ split,
-                                                    int32_t* __restrict__ ntrue, double* __restrict__ mcut_out) {
+// (normalized_cut.py:29-32); split iff mcut < T (:56).  One block per segment: column c of the
+// 40 partial columns is summed by 6 threads over interleaved task stripes, then in stripe order.
+#define SWF_STRIPES 6
+__global__ __launch_bounds__(AI_BLOCK) void k_sweep_final(const int32_t* __restrict__ ftask0, const int32_t* __restrict__ nosplit,
+                                                          const double* __restrict__ part, double T, double* __restrict__ costs,
+                                                          int32_t* __restrict__ kstar, int32_t* __restrict__ split,
+                                                          int32_t* __restrict__ ntrue, double* __restrict__ mcut_out) {
+  __shared__ double acc[SWF_STRIPES][AI_SWEEP_VALS];
   const int s = blockIdx.x;
-  const int lane = threadIdx.x;
   if (nosplit[s]) {
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
       split[s] = 0;
       kstar[s] = 0;
       ntrue[s] = 0;
       mcut_out[s] = INFINITY;
     }
-    if (lane < AI_NUM_CUTS) costs[s * AI_NUM_CUTS + lane] = NAN;
+    if (threadIdx.x < AI_NUM_CUTS) costs[s * AI_NUM_CUTS + threadIdx.x] = NAN;
     return;
   }
-  // lanes 0..39 each own one of the 40 partial columns
-  double acc = 0.0;
-  if (lane < AI_SWEEP_VALS)
-    for (int t = task0[s]; t < task0[s + 1]; ++t) acc += part[(size_t)t * AI_SWEEP_VALS + lane];
-  const double cutv = __shfl(acc, lane % AI_NUM_CUTS, 64);
-  const double av = __shfl(acc, AI_NUM_CUTS + lane % AI_NUM_CUTS, 64);
-  const double bv = __shfl(acc, 2 * AI_NUM_CUTS + lane % AI_NUM_CUTS, 64);
-  const double nv = __shfl(acc, 3 * AI_NUM_CUTS + lane % AI_NUM_CUTS, 64);
-  const double cost = __dadd_rn(__ddiv_rn(cutv, av), __ddiv_rn(cutv, bv));
-  if (lane < AI_NUM_CUTS) costs[s * AI_NUM_CUTS + lane] = cost;
-  // every lane walks the 10 costs (shuffles need the whole wave), lane 0 stores the decision
-  double best = INFINITY;
-  int kb = 0;
-  double nb = 0.0;
-  for (int k = 0; k < AI_NUM_CUTS; ++k) {
-    const double c = __shfl(cost, k, 64);
-    const double n = __shfl(nv, k, 64);
-    if (c < best) {
-      best = c;
-      kb = k;
-      nb = n;
-    }
+  const int c = threadIdx.x % AI_SWEEP_VALS, stripe = threadIdx.x / AI_SWEEP_VALS;
+  if (stripe < SWF_STRIPES) {
+    double a = 0.0;
+    for (int t = ftask0[s] + stripe; t < ftask0[s + 1]; t += SWF_STRIPES) a += part[(size_t)t * AI_SWEEP_VALS + c];
+    acc[stripe][c] = a;
   }
-  if (lane == 0) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double best = INFINITY;
+    int kb = 0;
+    double nb = 0.0;
+    for (int k = 0; k < AI_NUM_CUTS; ++k) {
+      double v[4];
+      for (int q = 0; q < 4; ++q) {
+        double a = 0.0;
+        for (int st = 0; st < SWF_STRIPES; ++st) a += acc[st][q * AI_NUM_CUTS + k];
+        v[q] = a;
+      }
+      const double cost = __dadd_rn(__ddiv_rn(v[0], v[1]), __ddiv_rn(v[0], v[2]));
+      costs[s * AI_NUM_CUTS + k] = cost;
+      if (cost < best) {
+        best = cost;
+        kb = k;
+        nb = v[3];
+      }
+    }
     kstar[s] = kb;
     mcut_out[s] = best;
     split[s] = (best < T) ? 1 : 0;
@@ -736,36 +838,33 @@ __global__ __launch_bounds__(64) void k_sweep_final(const int32_t* __restrict__ 
 }
 
 // ----------------------------------------------------------------------------- partition + rebuild
-__global__ __launch_bounds__(AI_BLOCK) void k_split_flags(const int32_t* __restrict__ task_seg, const int32_t* __restrict__ task_lo,
-                                                          const int32_t* __restrict__ task_hi, const int32_t* __restrict__ split,
+__global__ __launch_bounds__(AI_BLOCK) void k_split_flags(const Task* __restrict__ ctasks, const int32_t* __restrict__ split,
                                                           const int32_t* __restrict__ kstar, const uint8_t* __restrict__ bin,
                                                           int32_t* __restrict__ flag) {
-  const int t = blockIdx.x;
-  const int s = task_seg[t];
-  const int sp = split[s], ks = kstar[s];
-  for (int row = task_lo[t] + threadIdx.x; row < task_hi[t]; row += AI_BLOCK) flag[row] = (sp && (int)bin[row] > ks) ? 1 : 0;
+  const Task tk = ctasks[blockIdx.x];
+  const int sp = split[tk.z], ks = kstar[tk.z];
+  for (int row = tk.x + threadIdx.x; row < tk.y; row += AI_BLOCK) flag[row] = (sp && (int)bin[row] > ks) ? 1 : 0;
 }
 
 // Stable partition inside each parent (mask side first, normalized_cut.py:57-59).  Writes the
 // caller-order id of every row to its position in the final ordering and the row's index in the
 // next level's compact order (-1: the row's segment is finished).
-__global__ __launch_bounds__(AI_BLOCK) void k_partition(const int32_t* __restrict__ task_seg, const int32_t* __restrict__ task_lo,
-                                                        const int32_t* __restrict__ task_hi, const int32_t* __restrict__ seg_start,
+__global__ __launch_bounds__(AI_BLOCK) void k_partition(const Task* __restrict__ ctasks, const int32_t* __restrict__ seg_start,
                                                         const int32_t* __restrict__ seg_gstart, const int32_t* __restrict__ split,
-                                                        const int32_t* __restrict__ ntrue,
-                                                        const int32_t* __restrict__ childA, const int32_t* __restrict__ childB,
-                                                        const int32_t* __restrict__ flag, const int32_t* __restrict__ fscan,
-                                                        const int32_t* __restrict__ orig, int32_t* __restrict__ final_order,
-                                                        int32_t* __restrict__ map, int32_t* __restrict__ orig_next) {
-  const int t = blockIdx.x;
-  const int s = task_seg[t];
+                                                        const int32_t* __restrict__ ntrue, const int32_t* __restrict__ childA,
+                                                        const int32_t* __restrict__ childB, const int32_t* __restrict__ flag,
+                                                        const int32_t* __restrict__ fscan, const int32_t* __restrict__ orig,
+                                                        int32_t* __restrict__ final_order, int32_t* __restrict__ map,
+                                                        int32_t* __restrict__ orig_next) {
+  const Task tk = ctasks[blockIdx.x];
+  const int s = tk.z;
   const int s0 = seg_start[s], g0 = seg_gstart[s], nt = split[s] ? ntrue[s] : 0;
   const int cA = childA[s], cB = childB[s];
   const int f0 = fscan[s0];
-  for (int row = task_lo[t] + threadIdx.x; row < task_hi[t]; row += AI_BLOCK) {
+  for (int row = tk.x + threadIdx.x; row < tk.y; row += AI_BLOCK) {
     const int f = flag[row];
-    const int rt = fscan[row] - f0;            // mask-side rows before this one
-    const int rf = (row - s0) - rt;            // other-side rows before this one
+    const int rt = fscan[row] - f0;  // mask-side rows before this one
+    const int rf = (row - s0) - rt;  // other-side rows before this one
     const int newpos = f ? rt : nt + rf;
     const int32_t id = orig[row];
     final_order[g0 + newpos] = id;
@@ -777,6 +876,19 @@ __global__ __launch_bounds__(AI_BLOCK) void k_partition(const int32_t* __restric
     }
     map[row] = dst;
     if (dst >= 0) orig_next[dst] = id;
+  }
+}
+
+// parent_next[map[row]] = map[parent[row]]: a component's first row stays its first row under a
+// stable partition, and when the cut ran between whole components it lands in the same child
+__global__ __launch_bounds__(AI_BLOCK) void k_carry_parent(const int32_t* __restrict__ parent, const int32_t* __restrict__ map,
+                                                           int32_t n, int32_t* __restrict__ parent_next) {
+  const int i = blockIdx.x * AI_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const int32_t dst = map[i];
+  if (dst >= 0) {
+    const int32_t pr = map[parent[i]];
+    parent_next[dst] = (pr >= 0) ? pr : dst;
   }
 }
 
@@ -943,13 +1055,11 @@ static void tridiag_top(const double* a, const double* b, int m, double* theta_o
   std::vector<double> x(m);
   for (int i = 0; i < m; ++i) x[i] = 1.0 + 0.001 * ((i * 2654435761u) % 1000) / 1000.0;  // fixed, generic start
   for (int iter = 0; iter < 4; ++iter) {
-    // forward: L y = P x
-    for (int i = 0; i + 1 < m; ++i) {
+    for (int i = 0; i + 1 < m; ++i) {  // forward: L y = P x
       if (piv[i]) std::swap(x[i], x[i + 1]);
       x[i + 1] -= dl[i] * x[i];
     }
-    // backward: U z = y
-    x[m - 1] /= d[m - 1];
+    x[m - 1] /= d[m - 1];  // backward: U z = y
     if (m >= 2) x[m - 2] = (x[m - 2] - du[m - 2] * x[m - 1]) / d[m - 2];
     for (int i = m - 3; i >= 0; --i) x[i] = (x[i] - du[i] * x[i + 1] - du2[i] * x[i + 2]) / d[i];
     double n2 = 0.0;
@@ -963,13 +1073,23 @@ static void tridiag_top(const double* a, const double* b, int m, double* theta_o
 // ----------------------------------------------------------------------------- host: driver
 struct SegHost {
   int start, n, gstart;
-  int mode;  // 0 Lanczos, 1 null vector
+  int mode;     // 0 Lanczos, 1 null vector
+  int need_cc;  // 0: component labels were carried over a cut between whole components
 };
 
 static double now_ms() {
   using namespace std::chrono;
   return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
+
+struct TaskList {
+  int rows_per_task = 0;
+  int n = 0;
+  std::vector<Task> h;
+  std::vector<int32_t> h_seg0;
+  DevBuf<Task> d;
+  DevBuf<int32_t> d_seg0;
+};
 
 class Solver {
  public:
@@ -990,25 +1110,28 @@ class Solver {
   int S() const { return (int)segs.size(); }
   const int32_t *rowptr = nullptr, *col = nullptr, *orig = nullptr;
   const double* wraw = nullptr;
-  DevBuf<int32_t> b_rowptr[2], b_col[2], b_orig[2];
+  int32_t* parent = nullptr;  // component labels of the current level
+  DevBuf<int32_t> b_rowptr[2], b_col[2], b_orig[2], b_parent[2];
   DevBuf<double> b_wraw[2];
   DevBuf<int32_t> orig_id;  // identity when the graph has no permutation of its own
   int pp = 0;               // ping-pong index of the NEXT level's buffers
 
   // per-row work arrays
   DevBuf<double> deg, sinv, sinv2, u1, wm, ev, Y;
-  DevBuf<int32_t> parent, rcnt, rc, ex, flag, fscan, map, newcnt, scantmp, final_order;
+  DevBuf<int32_t> rcnt, rc, ex, flag, fscan, map, newcnt, scantmp, final_order;
   DevBuf<uint8_t> side, bin;
   // tasks
-  std::vector<int32_t> h_task_seg, h_task_lo, h_task_hi, h_task0, h_seg_start;
-  DevBuf<int32_t> task_seg, task_lo, task_hi, task0, seg_start;
-  int ntask = 0;
+  TaskList fine, coarse;
+  std::vector<TaskRange> h_cranges, h_segrange;
+  DevBuf<TaskRange> cranges, segrange;
+  std::vector<int32_t> h_seg_start;
+  DevBuf<int32_t> seg_start, factive, cactive;
   DevBuf<double> pvol, pA, pvolA, pvolB, psweep;
-  DevBuf<double2> pB;
+  DevBuf<double2> pB[2];
   DevBuf<MinMaxPart> pmm;
   // per-segment device arrays
-  DevBuf<int32_t> s_mode, s_frozen, s_m, s_ncomp, s_nosplit, s_kstar, s_split, s_ntrue, s_gstart, s_childA, s_childB, n_running;
-  DevBuf<double> s_g, s_b, s_rb, s_gp, s_rbp, s_alpha, s_theta, s_resid, s_vol, s_volA, s_volB, s_scale, s_thr, s_costs, s_mcut, s_cu;
+  DevBuf<int32_t> s_mode, s_needcc, s_frozen, s_m, s_ncomp, s_nosplit, s_kstar, s_split, s_ntrue, s_gstart, s_childA, s_childB, slots;
+  DevBuf<double> s_theta, s_resid, s_vol, s_volA, s_volB, s_scale, s_thr, s_costs, s_mcut, s_cu;
   // Lanczos history + vectors
   DevBuf<double> alpha_hist, b_hist, g_hist, coef;
   int mcap = 0;
@@ -1019,23 +1142,17 @@ class Solver {
     for (hipEvent_t e : evpool) (void)hipEventDestroy(e);
   }
 
-  SegDev segdev() {
-    SegDev d;
-    d.start = seg_start.p;
-    d.task0 = task0.p;
-    d.mode = s_mode.p;
-    d.frozen = s_frozen.p;
-    d.m = s_m.p;
-    d.g = s_g.p;
-    d.b = s_b.p;
-    d.rb = s_rb.p;
-    d.gp = s_gp.p;
-    d.rbp = s_rbp.p;
-    d.alpha = s_alpha.p;
-    d.theta = s_theta.p;
-    d.resid = s_resid.p;
-    d.vol = s_vol.p;
-    return d;
+  LzSeg lzseg() {
+    LzSeg L;
+    L.frozen = s_frozen.p;
+    L.m = s_m.p;
+    L.alpha_hist = alpha_hist.p;
+    L.b_hist = b_hist.p;
+    L.g_hist = g_hist.p;
+    L.factive = factive.p;
+    L.cactive = cactive.p;
+    L.mcap = mcap;
+    return L;
   }
 
   int alloc_rows() {
@@ -1047,7 +1164,8 @@ class Solver {
     AI_TRY(wm.alloc(e));
     AI_TRY(ev.alloc(n));
     AI_TRY(Y.alloc(n));
-    AI_TRY(parent.alloc(n));
+    AI_TRY(b_parent[0].alloc(n));
+    AI_TRY(b_parent[1].alloc(n));
     AI_TRY(rcnt.alloc(n));
     AI_TRY(rc.alloc(n + 1));
     AI_TRY(ex.alloc(n + 1));
@@ -1059,7 +1177,7 @@ class Solver {
     AI_TRY(final_order.alloc(n));
     AI_TRY(side.alloc(n));
     AI_TRY(bin.alloc(n));
-    AI_TRY(n_running.alloc(1));
+    AI_TRY(slots.alloc(AI_MAX_CHECKS));
     AI_TRY(work.alloc(2));
     AI_HIP(hipMemsetAsync(work.p, 0, 2 * sizeof(unsigned long long), st));
     return AI_OK;
@@ -1068,6 +1186,7 @@ class Solver {
   int alloc_segs(int S_) {
     const size_t s = (size_t)S_ + 1;
     AI_TRY(s_mode.ensure(s));
+    AI_TRY(s_needcc.ensure(s));
     AI_TRY(s_frozen.ensure(s));
     AI_TRY(s_m.ensure(s));
     AI_TRY(s_ncomp.ensure(s));
@@ -1078,12 +1197,6 @@ class Solver {
     AI_TRY(s_gstart.ensure(s));
     AI_TRY(s_childA.ensure(s));
     AI_TRY(s_childB.ensure(s));
-    AI_TRY(s_g.ensure(s));
-    AI_TRY(s_b.ensure(s));
-    AI_TRY(s_rb.ensure(s));
-    AI_TRY(s_gp.ensure(s));
-    AI_TRY(s_rbp.ensure(s));
-    AI_TRY(s_alpha.ensure(s));
     AI_TRY(s_theta.ensure(s));
     AI_TRY(s_resid.ensure(s));
     AI_TRY(s_vol.ensure(s));
@@ -1104,6 +1217,7 @@ class Solver {
     rowptr = A->rowptr;
     col = A->col;
     wraw = A->val;
+    parent = b_parent[0].p;
     if (A->orig) {
       orig = A->orig;
     } else {
@@ -1115,90 +1229,117 @@ class Solver {
     AI_HIP(hipMemcpyAsync(final_order.p, orig, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     na = n;
     segs.clear();
-    if (force_single_segment) segs.push_back(SegHost{0, n, 0, 0});
+    if (force_single_segment) segs.push_back(SegHost{0, n, 0, 0, 1});
     return AI_OK;
   }
 
-  // tasks + segment offsets for the current `segs`
-  int build_tasks() {
+  void make_tasks(TaskList& tl, int rows_per_task) {
     const int S_ = S();
-    h_task_seg.clear();
-    h_task_lo.clear();
-    h_task_hi.clear();
-    h_task0.assign(S_ + 1, 0);
-    h_seg_start.assign(S_ + 1, 0);
-    std::vector<int32_t> h_gstart(S_ + 1, 0);
+    tl.rows_per_task = rows_per_task;
+    tl.h.clear();
+    tl.h_seg0.assign(S_ + 1, 0);
     for (int s = 0; s < S_; ++s) {
-      h_task0[s] = (int32_t)h_task_seg.size();
-      h_seg_start[s] = segs[s].start;
-      h_gstart[s] = segs[s].gstart;
-      for (int lo = segs[s].start; lo < segs[s].start + segs[s].n; lo += AI_TASK_ROWS) {
-        h_task_seg.push_back(s);
-        h_task_lo.push_back(lo);
-        h_task_hi.push_back(std::min(lo + AI_TASK_ROWS, segs[s].start + segs[s].n));
+      tl.h_seg0[s] = (int32_t)tl.h.size();
+      bool first = true;
+      for (int lo = segs[s].start; lo < segs[s].start + segs[s].n; lo += rows_per_task) {
+        Task t;
+        t.x = lo;
+        t.y = std::min(lo + rows_per_task, segs[s].start + segs[s].n);
+        t.z = s;
+        t.w = first ? 1 : 0;
+        first = false;
+        tl.h.push_back(t);
       }
     }
-    h_task0[S_] = (int32_t)h_task_seg.size();
-    h_seg_start[S_] = S_ ? segs[S_ - 1].start + segs[S_ - 1].n : 0;
-    ntask = (int)h_task_seg.size();
-    AI_TRY(alloc_segs(S_));
-    AI_TRY(task_seg.ensure(ntask + 1));
-    AI_TRY(task_lo.ensure(ntask + 1));
-    AI_TRY(task_hi.ensure(ntask + 1));
-    AI_TRY(task0.ensure(S_ + 1));
-    AI_TRY(seg_start.ensure(S_ + 1));
-    AI_TRY(pvol.ensure(ntask + 1));
-    AI_TRY(pA.ensure(ntask + 1));
-    AI_TRY(pB.ensure(ntask + 1));
-    AI_TRY(pvolA.ensure(ntask + 1));
-    AI_TRY(pvolB.ensure(ntask + 1));
-    AI_TRY(psweep.ensure((size_t)(ntask + 1) * AI_SWEEP_VALS));
-    AI_TRY(pmm.ensure(ntask + 1));
-    if (ntask) {
-      AI_HIP(hipMemcpyAsync(task_seg.p, h_task_seg.data(), ntask * sizeof(int32_t), hipMemcpyHostToDevice, st));
-      AI_HIP(hipMemcpyAsync(task_lo.p, h_task_lo.data(), ntask * sizeof(int32_t), hipMemcpyHostToDevice, st));
-      AI_HIP(hipMemcpyAsync(task_hi.p, h_task_hi.data(), ntask * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    tl.h_seg0[S_] = (int32_t)tl.h.size();
+    tl.n = (int)tl.h.size();
+  }
+
+  // task lists + segment offsets for the current `segs`
+  int build_tasks() {
+    const int S_ = S();
+    make_tasks(fine, AI_FINE_ROWS);
+    make_tasks(coarse, AI_COARSE_ROWS);
+    h_seg_start.assign(S_ + 1, 0);
+    std::vector<int32_t> h_gstart(S_ + 1, 0), h_needcc(S_ + 1, 0);
+    h_segrange.assign(S_ + 1, TaskRange{0, 0, 0, 0});
+    for (int s = 0; s < S_; ++s) {
+      h_seg_start[s] = segs[s].start;
+      h_gstart[s] = segs[s].gstart;
+      h_needcc[s] = segs[s].need_cc;
+      h_segrange[s] = TaskRange{fine.h_seg0[s], fine.h_seg0[s + 1], coarse.h_seg0[s], coarse.h_seg0[s + 1]};
     }
-    AI_HIP(hipMemcpyAsync(task0.p, h_task0.data(), (S_ + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    h_seg_start[S_] = S_ ? segs[S_ - 1].start + segs[S_ - 1].n : 0;
+    h_cranges.resize(coarse.n);
+    for (int t = 0; t < coarse.n; ++t) h_cranges[t] = h_segrange[coarse.h[t].z];
+    AI_TRY(alloc_segs(S_));
+    AI_TRY(fine.d.ensure(fine.n + 1));
+    AI_TRY(fine.d_seg0.ensure(S_ + 1));
+    AI_TRY(coarse.d.ensure(coarse.n + 1));
+    AI_TRY(coarse.d_seg0.ensure(S_ + 1));
+    AI_TRY(cranges.ensure(coarse.n + 1));
+    AI_TRY(segrange.ensure(S_ + 1));
+    AI_TRY(seg_start.ensure(S_ + 1));
+    AI_TRY(factive.ensure(fine.n + 1));
+    AI_TRY(cactive.ensure(coarse.n + 1));
+    AI_TRY(pvol.ensure(fine.n + 1));
+    AI_TRY(pA.ensure(fine.n + 1));
+    AI_TRY(psweep.ensure((size_t)(fine.n + 1) * AI_SWEEP_VALS));
+    AI_TRY(pB[0].ensure(coarse.n + 1));
+    AI_TRY(pB[1].ensure(coarse.n + 1));
+    AI_TRY(pvolA.ensure(coarse.n + 1));
+    AI_TRY(pvolB.ensure(coarse.n + 1));
+    AI_TRY(pmm.ensure(coarse.n + 1));
+    AI_HIP(hipMemcpyAsync(fine.d.p, fine.h.data(), fine.n * sizeof(Task), hipMemcpyHostToDevice, st));
+    AI_HIP(hipMemcpyAsync(coarse.d.p, coarse.h.data(), coarse.n * sizeof(Task), hipMemcpyHostToDevice, st));
+    AI_HIP(hipMemcpyAsync(cranges.p, h_cranges.data(), coarse.n * sizeof(TaskRange), hipMemcpyHostToDevice, st));
+    AI_HIP(hipMemcpyAsync(segrange.p, h_segrange.data(), (S_ + 1) * sizeof(TaskRange), hipMemcpyHostToDevice, st));
+    AI_HIP(hipMemcpyAsync(fine.d_seg0.p, fine.h_seg0.data(), (S_ + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    AI_HIP(hipMemcpyAsync(coarse.d_seg0.p, coarse.h_seg0.data(), (S_ + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
     AI_HIP(hipMemcpyAsync(seg_start.p, h_seg_start.data(), (S_ + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
     AI_HIP(hipMemcpyAsync(s_gstart.p, h_gstart.data(), (S_ + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    // the host vectors must outlive the copies
-    AI_HIP(hipStreamSynchronize(st));
+    AI_HIP(hipMemcpyAsync(s_needcc.p, h_needcc.data(), (S_ + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    AI_HIP(hipStreamSynchronize(st));  // the host vectors must outlive the copies
     return AI_OK;
   }
 
   // degrees, scaled matrix, u1, connected components -> segs[s].mode
   int prepare(bool want_cc) {
     const int S_ = S();
-    hipLaunchKernelGGL(k_degree, dim3(ntask), dim3(AI_BLOCK), 0, st, task_seg.p, task_lo.p, task_hi.p, rowptr, wraw, deg.p, sinv.p, pvol.p);
+    hipLaunchKernelGGL(k_degree, dim3(fine.n), dim3(AI_BLOCK), 0, st, fine.d.p, rowptr, wraw, deg.p, sinv.p, pvol.p);
     AI_KERNEL_CHECK();
-    hipLaunchKernelGGL(k_seg_sum, dim3(S_), dim3(AI_BLOCK), 0, st, task0.p, pvol.p, s_vol.p);
+    hipLaunchKernelGGL(k_seg_sum, dim3(S_), dim3(AI_BLOCK), 0, st, fine.d_seg0.p, pvol.p, s_vol.p);
     AI_KERNEL_CHECK();
-    hipLaunchKernelGGL(k_scale, dim3(ntask), dim3(AI_BLOCK), 0, st, task_seg.p, task_lo.p, task_hi.p, rowptr, col, wraw, deg.p, sinv.p,
-                       s_vol.p, wm.p, sinv2.p, u1.p);
+    hipLaunchKernelGGL(k_scale, dim3(fine.n), dim3(AI_BLOCK), 0, st, fine.d.p, rowptr, col, wraw, deg.p, sinv.p, s_vol.p, wm.p, sinv2.p, u1.p);
     AI_KERNEL_CHECK();
     std::vector<int32_t> ncomp(S_, 1);
     if (want_cc) {
-      const unsigned gr = (unsigned)((na + AI_BLOCK - 1) / AI_BLOCK);
-      const unsigned ge = (unsigned)(((int64_t)na * AI_LPR + AI_BLOCK - 1) / AI_BLOCK);
-      hipLaunchKernelGGL(k_cc_init, dim3(gr), dim3(AI_BLOCK), 0, st, parent.p, na);
-      AI_KERNEL_CHECK();
-      hipLaunchKernelGGL(k_cc_hook, dim3(ge), dim3(AI_BLOCK), 0, st, rowptr, col, na, parent.p);
-      AI_KERNEL_CHECK();
-      hipLaunchKernelGGL(k_cc_compress, dim3(gr), dim3(AI_BLOCK), 0, st, parent.p, na);
-      AI_KERNEL_CHECK();
+      bool any = false;
+      for (auto& s : segs) any |= (s.need_cc != 0);
+      if (any) {
+        hipLaunchKernelGGL(k_cc_init, dim3(fine.n), dim3(AI_BLOCK), 0, st, fine.d.p, s_needcc.p, rowptr, col, parent);
+        AI_KERNEL_CHECK();
+        hipLaunchKernelGGL(k_cc_hook, dim3(fine.n), dim3(AI_BLOCK), 0, st, fine.d.p, s_needcc.p, rowptr, col, parent);
+        AI_KERNEL_CHECK();
+        hipLaunchKernelGGL(k_cc_compress, dim3(coarse.n), dim3(AI_BLOCK), 0, st, coarse.d.p, s_needcc.p, parent);
+        AI_KERNEL_CHECK();
+      }
       AI_HIP(hipMemsetAsync(s_ncomp.p, 0, (size_t)S_ * sizeof(int32_t), st));
-      hipLaunchKernelGGL(k_cc_count, dim3(ntask), dim3(AI_BLOCK), 0, st, task_seg.p, task_lo.p, task_hi.p, parent.p, s_ncomp.p);
+      hipLaunchKernelGGL(k_cc_count, dim3(coarse.n), dim3(AI_BLOCK), 0, st, coarse.d.p, parent, s_ncomp.p);
       AI_KERNEL_CHECK();
       AI_HIP(hipMemcpyAsync(ncomp.data(), s_ncomp.p, (size_t)S_ * sizeof(int32_t), hipMemcpyDeviceToHost, st));
       AI_HIP(hipStreamSynchronize(st));
     }
-    std::vector<int32_t> mode(S_);
+    std::vector<int32_t> mode(S_), fa(fine.n), ca(coarse.n);
     for (int s = 0; s < S_; ++s) {
       segs[s].mode = (ncomp[s] > 1) ? 1 : 0;
       mode[s] = segs[s].mode;
     }
+    for (int t = 0; t < fine.n; ++t) fa[t] = (mode[fine.h[t].z] == 0) ? 1 : 0;
+    for (int t = 0; t < coarse.n; ++t) ca[t] = (mode[coarse.h[t].z] == 0) ? 1 : 0;
     AI_HIP(hipMemcpyAsync(s_mode.p, mode.data(), (size_t)S_ * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    AI_HIP(hipMemcpyAsync(factive.p, fa.data(), (size_t)fine.n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    AI_HIP(hipMemcpyAsync(cactive.p, ca.data(), (size_t)coarse.n * sizeof(int32_t), hipMemcpyHostToDevice, st));
     AI_HIP(hipStreamSynchronize(st));
     return AI_OK;
   }
@@ -1210,20 +1351,19 @@ class Solver {
     if (!any) return AI_OK;
     const unsigned gr = (unsigned)((na + AI_BLOCK - 1) / AI_BLOCK);
     AI_HIP(hipMemsetAsync(rcnt.p, 0, (size_t)na * sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_null_rootcount, dim3(ntask), dim3(AI_BLOCK), 0, st, task_seg.p, task_lo.p, task_hi.p, s_mode.p, parent.p, rcnt.p);
+    hipLaunchKernelGGL(k_null_rootcount, dim3(coarse.n), dim3(AI_BLOCK), 0, st, coarse.d.p, s_mode.p, (const int32_t*)parent, rcnt.p);
     AI_KERNEL_CHECK();
-    hipLaunchKernelGGL(k_null_rootvals, dim3(gr), dim3(AI_BLOCK), 0, st, parent.p, rcnt.p, na, rc.p);
+    hipLaunchKernelGGL(k_null_rootvals, dim3(gr), dim3(AI_BLOCK), 0, st, (const int32_t*)parent, rcnt.p, na, rc.p);
     AI_KERNEL_CHECK();
     AI_TRY(ai_exclusive_scan_i32(st, rc.p, ex.p, na, scantmp.p));
-    hipLaunchKernelGGL(k_null_side, dim3(ntask), dim3(AI_BLOCK), 0, st, task_seg.p, task_lo.p, task_hi.p, s_mode.p, seg_start.p, parent.p,
-                       rcnt.p, ex.p, deg.p, side.p, pvolA.p, pvolB.p);
+    hipLaunchKernelGGL(k_null_side, dim3(coarse.n), dim3(AI_BLOCK), 0, st, coarse.d.p, s_mode.p, seg_start.p, (const int32_t*)parent, rcnt.p,
+                       ex.p, deg.p, side.p, pvolA.p, pvolB.p);
     AI_KERNEL_CHECK();
-    hipLaunchKernelGGL(k_seg_sum, dim3(S_), dim3(AI_BLOCK), 0, st, task0.p, pvolA.p, s_volA.p);
+    hipLaunchKernelGGL(k_seg_sum, dim3(S_), dim3(AI_BLOCK), 0, st, coarse.d_seg0.p, pvolA.p, s_volA.p);
     AI_KERNEL_CHECK();
-    hipLaunchKernelGGL(k_seg_sum, dim3(S_), dim3(AI_BLOCK), 0, st, task0.p, pvolB.p, s_volB.p);
+    hipLaunchKernelGGL(k_seg_sum, dim3(S_), dim3(AI_BLOCK), 0, st, coarse.d_seg0.p, pvolB.p, s_volB.p);
     AI_KERNEL_CHECK();
-    hipLaunchKernelGGL(k_null_vec, dim3(ntask), dim3(AI_BLOCK), 0, st, task_seg.p, task_lo.p, task_hi.p, s_mode.p, s_volA.p, s_volB.p,
-                       deg.p, side.p, ev.p);
+    hipLaunchKernelGGL(k_null_vec, dim3(coarse.n), dim3(AI_BLOCK), 0, st, coarse.d.p, s_mode.p, s_volA.p, s_volB.p, deg.p, side.p, ev.p);
     AI_KERNEL_CHECK();
     for (auto& s : segs) stats.null_solves += (s.mode == 1);
     return AI_OK;
@@ -1244,18 +1384,25 @@ class Solver {
     return AI_OK;
   }
 
+  int launch_spmv(int j) {
+    hipLaunchKernelGGL(k_lz_spmv, dim3(fine.n), dim3(AI_BLOCK), 0, st, fine.d.p, factive.p, fine.n, rowptr, col, wm.p, sinv2.p,
+                       (const double*)vec(j), Y.p, pA.p);
+    AI_KERNEL_CHECK();
+    return AI_OK;
+  }
+
   // Lock-step Lanczos over every mode-0 segment, then Ritz vectors into ev.
   // theta_out / iters_out / resid_out (optional): values of segment 0.
   int lanczos(double* theta_out, int* iters_out, double* resid_out) {
     const int S_ = S();
     int nl = 0, max_n = 0, min_n = 1 << 30;
-    int64_t lz_rows = 0;
+    std::set<int> forced;  // steps at which some segment reaches its own dimension
     for (auto& s : segs)
       if (s.mode == 0) {
         ++nl;
         max_n = std::max(max_n, s.n);
         min_n = std::min(min_n, s.n);
-        lz_rows += s.n;
+        forced.insert(std::min(opt.max_iter, s.n - 1));
       }
     if (nl == 0) return AI_OK;
     stats.lanczos_solves += nl;
@@ -1269,22 +1416,44 @@ class Solver {
     if (slab_stride == 0) slab_stride = (size_t)na;
     AI_HIP(hipMemsetAsync(s_frozen.p, 0, (size_t)S_ * sizeof(int32_t), st));
     AI_HIP(hipMemsetAsync(s_m.p, 0, (size_t)S_ * sizeof(int32_t), st));
-    AI_HIP(hipMemsetAsync(s_g.p, 0, (size_t)S_ * sizeof(double), st));
-    AI_HIP(hipMemsetAsync(s_rb.p, 0, (size_t)S_ * sizeof(double), st));
-    AI_HIP(hipMemsetAsync(n_running.p, 0, sizeof(int32_t), st));
-    SegDev sd = segdev();
+    AI_HIP(hipMemsetAsync(s_resid.p, 0, (size_t)S_ * sizeof(double), st));
+    AI_HIP(hipMemsetAsync(slots.p, 0, AI_MAX_CHECKS * sizeof(int32_t), st));
+    LzSeg L = lzseg();
     AI_TRY(ensure_vec(0));
     AI_TRY(ensure_vec(1));
     AI_HIP(hipEventRecord(ctx->ev[0], st));
-    hipLaunchKernelGGL(k_lz_init, dim3(ntask), dim3(AI_BLOCK), 0, st, task_seg.p, task_lo.p, task_hi.p, s_mode.p, orig, u1.p, vec(0), pB.p);
-    AI_KERNEL_CHECK();
-    hipLaunchKernelGGL(k_lz_norm_check, dim3(S_), dim3(64), 0, st, sd, (const double2*)pB.p, alpha_hist.p, b_hist.p, g_hist.p, mcap, 0, 0,
-                       opt.tol, opt.max_iter, n_running.p, rowptr, work.p);
+    hipLaunchKernelGGL(k_lz_init, dim3(coarse.n), dim3(AI_BLOCK), 0, st, coarse.d.p, cactive.p, orig, u1.p, vec(0), pB[0].p);
     AI_KERNEL_CHECK();
     const bool dense_checks = (min_n <= 512);
     int next_check = dense_checks ? 1 : opt.check_every;
-    int steps = 0;
-    for (int j = 0; j < mcap; ++j) {
+    int steps = 0, nchecks = 0, last_check_m = 0;
+    // Checks are asynchronous: the check kernel's counter is copied to pinned host memory behind
+    // an event and read a few steps later, so the stream never drains.  A finished segment's
+    // blocks exit at their activity flag, so steps launched past the end cost next to nothing;
+    // the host still never runs more than AI_RUNAHEAD steps past an unread check.
+    const int AI_RUNAHEAD = 6;
+    struct Pending { int slot, m; };
+    std::vector<Pending> pending;  // FIFO of in-flight checks
+    size_t phead = 0;
+    bool done = false;
+    auto reap = [&](bool block) -> int {
+      while (phead < pending.size()) {
+        const Pending pc = pending[phead];
+        hipEvent_t e = ctx->chk_ev[pc.slot % AI_CHECK_DEPTH];
+        if (block) {
+          AI_HIP(hipEventSynchronize(e));
+        } else {
+          hipError_t q = hipEventQuery(e);
+          if (q == hipErrorNotReady) break;
+          AI_HIP(q);
+        }
+        if (ctx->pinned[pc.slot % AI_PINNED_INTS] == 0) done = true;
+        ++phead;
+        block = false;
+      }
+      return AI_OK;
+    };
+    for (int j = 0; j < mcap && !done; ++j) {
       AI_TRY(ensure_vec(j + 1));
       if (time_spmv) {
         while (evpool.size() < (size_t)2 * (j + 1)) {
@@ -1294,32 +1463,35 @@ class Solver {
         }
         AI_HIP(hipEventRecord(evpool[2 * j], st));
       }
-      hipLaunchKernelGGL(k_lz_spmv, dim3(ntask), dim3(AI_BLOCK), 0, st, task_seg.p, task_lo.p, task_hi.p, ntask, s_mode.p, s_frozen.p,
-                         s_g.p, s_rb.p, rowptr, col, wm.p, sinv2.p, u1.p, (const double*)vec(j), Y.p, pA.p);
-      AI_KERNEL_CHECK();
+      AI_TRY(launch_spmv(j));
       if (time_spmv) AI_HIP(hipEventRecord(evpool[2 * j + 1], st));
-      hipLaunchKernelGGL(k_lz_alpha, dim3(S_), dim3(AI_BLOCK), 0, st, sd, (const double*)pA.p, alpha_hist.p, mcap, j);
-      AI_KERNEL_CHECK();
-      hipLaunchKernelGGL(k_lz_update, dim3(ntask), dim3(AI_BLOCK), 0, st, task_seg.p, task_lo.p, task_hi.p, sd, u1.p, (const double*)Y.p,
-                         (const double*)vec(j), (const double*)vec(j > 0 ? j - 1 : 0), vec(j + 1), pB.p);
-      AI_KERNEL_CHECK();
-      const int m = j + 1;
-      const bool check = (m >= next_check) || (m == mcap);
-      AI_HIP(hipMemsetAsync(n_running.p, 0, sizeof(int32_t), st));
-      hipLaunchKernelGGL(k_lz_norm_check, dim3(S_), dim3(64), 0, st, sd, (const double2*)pB.p, alpha_hist.p, b_hist.p, g_hist.p, mcap, m,
-                         check ? 1 : 0, opt.tol, opt.max_iter, n_running.p, rowptr, work.p);
+      hipLaunchKernelGGL(k_lz_update, dim3(coarse.n), dim3(AI_BLOCK), 0, st, coarse.d.p, cranges.p, L, j, (const double*)pA.p,
+                         (const double2*)pB[j & 1].p, pB[(j + 1) & 1].p, u1.p, (const double*)Y.p, (const double*)vec(j),
+                         (const double*)vec(j > 0 ? j - 1 : 0), vec(j + 1));
       AI_KERNEL_CHECK();
       ++steps;
-      if (check || dense_checks) {
-        int32_t running = 0;
-        AI_HIP(hipMemcpyAsync(&running, n_running.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        AI_HIP(hipStreamSynchronize(st));
-        if (check) next_check = dense_checks ? m + 1 : m + std::max(opt.check_every, (m / 8 / opt.check_every) * opt.check_every);
-        if (running == 0) break;
+      const int m = j + 1;
+      const bool check = dense_checks || (m >= next_check) || (m == mcap) || forced.count(m) > 0;
+      if (check && nchecks < AI_MAX_CHECKS) {
+        // at most AI_CHECK_DEPTH checks in flight (their events and pinned slots are recycled)
+        if (pending.size() - phead >= (size_t)AI_CHECK_DEPTH - 1) AI_TRY(reap(true));
+        hipLaunchKernelGGL(k_lz_check, dim3(S_), dim3(64), (size_t)2 * m * sizeof(double), st, seg_start.p, segrange.p, s_mode.p, L,
+                           (const double2*)pB[(j + 1) & 1].p, m, opt.tol, opt.max_iter, m - last_check_m, rowptr, s_theta.p, s_resid.p,
+                           slots.p + nchecks, work.p);
+        AI_KERNEL_CHECK();
+        AI_HIP(hipMemcpyAsync(&ctx->pinned[nchecks % AI_PINNED_INTS], slots.p + nchecks, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        AI_HIP(hipEventRecord(ctx->chk_ev[nchecks % AI_CHECK_DEPTH], st));
+        pending.push_back(Pending{nchecks, m});
+        ++nchecks;
+        last_check_m = m;
+        if (m >= next_check) next_check = m + std::max(opt.check_every, (m / 8 / opt.check_every) * opt.check_every);
       }
+      // read whatever has arrived; block only when the oldest unread check is AI_RUNAHEAD steps old
+      const bool must = (phead < pending.size()) && (m - pending[phead].m >= AI_RUNAHEAD || m == mcap);
+      AI_TRY(reap(must));
     }
+    while (phead < pending.size()) AI_TRY(reap(true));
     stats.lanczos_steps += steps;
-    (void)lz_rows;
     if (time_spmv) {
       AI_HIP(hipStreamSynchronize(st));
       for (int j = 0; j < steps; ++j) {
@@ -1329,10 +1501,11 @@ class Solver {
       }
     }
     // ---- Ritz coefficients on the host (tiny), Ritz vectors on the device
-    std::vector<int32_t> h_m(S_);
+    std::vector<int32_t> h_m(S_), h_frozen(S_);
     std::vector<double> h_a((size_t)S_ * mcap), h_b((size_t)S_ * (mcap + 1)), h_g((size_t)S_ * (mcap + 1)), h_coef((size_t)S_ * mcap, 0.0),
         h_cu(S_, 0.0), h_resid(S_, 0.0);
     AI_HIP(hipMemcpyAsync(h_m.data(), s_m.p, (size_t)S_ * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    AI_HIP(hipMemcpyAsync(h_frozen.data(), s_frozen.p, (size_t)S_ * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     AI_HIP(hipMemcpyAsync(h_a.data(), alpha_hist.p, h_a.size() * sizeof(double), hipMemcpyDeviceToHost, st));
     AI_HIP(hipMemcpyAsync(h_b.data(), b_hist.p, h_b.size() * sizeof(double), hipMemcpyDeviceToHost, st));
     AI_HIP(hipMemcpyAsync(h_g.data(), g_hist.p, h_g.size() * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1342,7 +1515,13 @@ class Solver {
     std::vector<double> sv;
     for (int s = 0; s < S_; ++s) {
       if (segs[s].mode != 0) continue;
-      const int m = h_m[s];
+      int m = h_m[s];
+      if (!h_frozen[s]) {
+        // the check budget ran out before this segment was frozen: use everything computed
+        m = steps;
+        h_m[s] = m;
+        ++stats.unconverged;
+      }
       if (m <= 0) {
         ai_set_error("internal: Lanczos segment %d finished with an empty tridiagonal matrix", s);
         return AI_ERR_INTERNAL;
@@ -1361,7 +1540,7 @@ class Solver {
       }
       h_cu[s] = cu;
       // a residual above tol is a failure only if T is smaller than the segment's own dimension
-      if (h_resid[s] > opt.tol && m < segs[s].n - 1) ++stats.unconverged;
+      if (h_frozen[s] && h_resid[s] > opt.tol && m < segs[s].n - 1) ++stats.unconverged;
       stats.max_resid = std::max(stats.max_resid, h_resid[s]);
       if (s == 0) {
         if (theta_out) *theta_out = theta;
@@ -1369,11 +1548,12 @@ class Solver {
         if (resid_out) *resid_out = h_resid[s];
       }
     }
+    AI_HIP(hipMemcpyAsync(s_m.p, h_m.data(), (size_t)S_ * sizeof(int32_t), hipMemcpyHostToDevice, st));
     AI_HIP(hipMemcpyAsync(coef.p, h_coef.data(), h_coef.size() * sizeof(double), hipMemcpyHostToDevice, st));
     AI_HIP(hipMemcpyAsync(s_cu.p, h_cu.data(), (size_t)S_ * sizeof(double), hipMemcpyHostToDevice, st));
     for (int j0 = 0; j0 < max_m; j0 += AI_SLAB_VECS) {
-      hipLaunchKernelGGL(k_ritz, dim3(ntask), dim3(AI_BLOCK), 0, st, task_seg.p, task_lo.p, task_hi.p, s_mode.p, s_m.p, coef.p, mcap, s_cu.p,
-                         u1.p, (const double*)slabs[(size_t)j0 / AI_SLAB_VECS], slab_stride, j0, AI_SLAB_VECS, j0 == 0 ? 1 : 0, ev.p);
+      hipLaunchKernelGGL(k_ritz, dim3(coarse.n), dim3(AI_BLOCK), 0, st, coarse.d.p, s_mode.p, s_m.p, coef.p, mcap, s_cu.p, u1.p,
+                         (const double*)slabs[(size_t)j0 / AI_SLAB_VECS], slab_stride, j0, AI_SLAB_VECS, j0 == 0 ? 1 : 0, ev.p);
       AI_KERNEL_CHECK();
     }
     AI_HIP(hipEventRecord(ctx->ev[1], st));
@@ -1384,27 +1564,28 @@ class Solver {
     return AI_OK;
   }
 
-  // min/max, bins, 10 costs, decision -> host vectors split / ntrue (raw = 1: ev used as given)
-  int sweep(double T, int raw, std::vector<int32_t>& h_split, std::vector<int32_t>& h_ntrue) {
+  // min/max, bins, 10 costs, decision -> host vectors (raw = 1: ev used as given)
+  int sweep(double T, int raw, std::vector<int32_t>& h_split, std::vector<int32_t>& h_ntrue, std::vector<double>& h_mcut) {
     const int S_ = S();
     AI_HIP(hipEventRecord(ctx->ev[2], st));
-    hipLaunchKernelGGL(k_minmax, dim3(ntask), dim3(AI_BLOCK), 0, st, task_seg.p, task_lo.p, task_hi.p, s_mode.p, ev.p, orig, pmm.p);
+    hipLaunchKernelGGL(k_minmax, dim3(coarse.n), dim3(AI_BLOCK), 0, st, coarse.d.p, ev.p, orig, pmm.p);
     AI_KERNEL_CHECK();
-    hipLaunchKernelGGL(k_minmax_final, dim3((S_ + 63) / 64), dim3(64), 0, st, task0.p, s_mode.p, pmm.p, S_, raw, s_scale.p, s_nosplit.p, s_thr.p);
+    hipLaunchKernelGGL(k_minmax_final, dim3((S_ + 63) / 64), dim3(64), 0, st, coarse.d_seg0.p, pmm.p, S_, raw, s_scale.p, s_nosplit.p, s_thr.p);
     AI_KERNEL_CHECK();
-    hipLaunchKernelGGL(k_bin, dim3(ntask), dim3(AI_BLOCK), 0, st, task_seg.p, task_lo.p, task_hi.p, s_scale.p, s_thr.p, ev.p, bin.p);
+    hipLaunchKernelGGL(k_bin, dim3(coarse.n), dim3(AI_BLOCK), 0, st, coarse.d.p, s_scale.p, s_thr.p, ev.p, bin.p);
     AI_KERNEL_CHECK();
-    hipLaunchKernelGGL(k_sweep, dim3(ntask), dim3(AI_BLOCK), 0, st, task_seg.p, task_lo.p, task_hi.p, s_nosplit.p, rowptr, col, wraw, deg.p,
-                       bin.p, psweep.p);
+    hipLaunchKernelGGL(k_sweep, dim3(fine.n), dim3(AI_BLOCK), 0, st, fine.d.p, s_nosplit.p, rowptr, col, wraw, deg.p, bin.p, psweep.p);
     AI_KERNEL_CHECK();
-    hipLaunchKernelGGL(k_sweep_final, dim3(S_), dim3(64), 0, st, task0.p, s_nosplit.p, psweep.p, T, s_costs.p, s_kstar.p, s_split.p, s_ntrue.p,
-                       s_mcut.p);
+    hipLaunchKernelGGL(k_sweep_final, dim3(S_), dim3(AI_BLOCK), 0, st, fine.d_seg0.p, s_nosplit.p, psweep.p, T, s_costs.p, s_kstar.p, s_split.p,
+                       s_ntrue.p, s_mcut.p);
     AI_KERNEL_CHECK();
     AI_HIP(hipEventRecord(ctx->ev[3], st));
     h_split.resize(S_);
     h_ntrue.resize(S_);
+    h_mcut.resize(S_);
     AI_HIP(hipMemcpyAsync(h_split.data(), s_split.p, (size_t)S_ * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     AI_HIP(hipMemcpyAsync(h_ntrue.data(), s_ntrue.p, (size_t)S_ * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    AI_HIP(hipMemcpyAsync(h_mcut.data(), s_mcut.p, (size_t)S_ * sizeof(double), hipMemcpyDeviceToHost, st));
     AI_HIP(hipStreamSynchronize(st));
     float ms = 0.f;
     AI_HIP(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
@@ -1424,7 +1605,7 @@ static bool eligible(int n, int64_t n_orig, double split_lim) {
 static void fill_opts(Solver& S, const ai_ncut_opts* opts) {
   if (!opts) return;
   if (opts->tol > 0.0) S.opt.tol = opts->tol;
-  if (opts->max_iter > 0) S.opt.max_iter = opts->max_iter;
+  if (opts->max_iter > 0) S.opt.max_iter = std::min(opts->max_iter, 4000);  // T_m must fit the check kernel's 64 KB of LDS
   if (opts->check_every > 0) S.opt.check_every = opts->check_every;
   S.time_spmv = (opts->reserved & 1) != 0;
 }
@@ -1443,11 +1624,12 @@ extern "C" int ai_ncut(ai_ctx* ctx, const ai_csr* csr, int64_t num_points_orig, 
   AI_TRY(S.begin(false));
   std::vector<int32_t> leaf_starts;
   if (eligible(n, num_points_orig, split_lim))
-    S.segs.push_back(SegHost{0, n, 0, 0});
+    S.segs.push_back(SegHost{0, n, 0, 0, 1});
   else
     leaf_starts.push_back(0);
   hipStream_t st = ctx->stream;
   std::vector<int32_t> h_split, h_ntrue;
+  std::vector<double> h_mcut;
   while (S.S() > 0) {
     ++S.stats.levels;
     AI_TRY(S.build_tasks());
@@ -1456,12 +1638,13 @@ extern "C" int ai_ncut(ai_ctx* ctx, const ai_csr* csr, int64_t num_points_orig, 
     AI_HIP(hipEventRecord(ctx->ev[5], st));
     AI_TRY(S.null_vectors());
     AI_TRY(S.lanczos(nullptr, nullptr, nullptr));
-    AI_TRY(S.sweep(T, 0, h_split, h_ntrue));
+    AI_TRY(S.sweep(T, 0, h_split, h_ntrue, h_mcut));
     // ---- children (deeper calls use split_lim = 0.01: normalized_cut.py:57-58 rely on the default)
     const int S_ = S.S();
     std::vector<SegHost> next;
     std::vector<int32_t> cA(S_, -1), cB(S_, -1);
     int cstart = 0;
+    bool any_carry = false;
     for (int s = 0; s < S_; ++s) {
       const SegHost& sg = S.segs[s];
       if (!h_split[s]) {
@@ -1473,17 +1656,21 @@ extern "C" int ai_ncut(ai_ctx* ctx, const ai_csr* csr, int64_t num_points_orig, 
         ai_set_error("internal: split of segment %d produced an empty side (%d / %d)", s, na_, nb_);
         return AI_ERR_INTERNAL;
       }
+      // a null-vector cut of cost exactly 0 runs between whole components: their labels stay valid
+      const int carry = (sg.mode == 1 && h_mcut[s] == 0.0) ? 1 : 0;
       if (eligible(na_, num_points_orig, 0.01)) {
         cA[s] = cstart;
-        next.push_back(SegHost{cstart, na_, sg.gstart, 0});
+        next.push_back(SegHost{cstart, na_, sg.gstart, 0, carry ? 0 : 1});
         cstart += na_;
+        any_carry |= (carry != 0);
       } else {
         leaf_starts.push_back(sg.gstart);
       }
       if (eligible(nb_, num_points_orig, 0.01)) {
         cB[s] = cstart;
-        next.push_back(SegHost{cstart, nb_, sg.gstart + na_, 0});
+        next.push_back(SegHost{cstart, nb_, sg.gstart + na_, 0, carry ? 0 : 1});
         cstart += nb_;
+        any_carry |= (carry != 0);
       } else {
         leaf_starts.push_back(sg.gstart + na_);
       }
@@ -1491,17 +1678,22 @@ extern "C" int ai_ncut(ai_ctx* ctx, const ai_csr* csr, int64_t num_points_orig, 
     AI_HIP(hipEventRecord(ctx->ev[6], st));
     AI_HIP(hipMemcpyAsync(S.s_childA.p, cA.data(), (size_t)S_ * sizeof(int32_t), hipMemcpyHostToDevice, st));
     AI_HIP(hipMemcpyAsync(S.s_childB.p, cB.data(), (size_t)S_ * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_split_flags, dim3(S.ntask), dim3(AI_BLOCK), 0, st, S.task_seg.p, S.task_lo.p, S.task_hi.p, S.s_split.p, S.s_kstar.p,
-                       S.bin.p, S.flag.p);
+    hipLaunchKernelGGL(k_split_flags, dim3(S.coarse.n), dim3(AI_BLOCK), 0, st, S.coarse.d.p, S.s_split.p, S.s_kstar.p, S.bin.p, S.flag.p);
     AI_KERNEL_CHECK();
     AI_TRY(ai_exclusive_scan_i32(st, S.flag.p, S.fscan.p, S.na, S.scantmp.p));
     const int pp = S.pp;
     AI_TRY(S.b_orig[pp].ensure((size_t)std::max(cstart, 1)));
-    hipLaunchKernelGGL(k_partition, dim3(S.ntask), dim3(AI_BLOCK), 0, st, S.task_seg.p, S.task_lo.p, S.task_hi.p, S.seg_start.p, S.s_gstart.p,
-                       S.s_split.p, S.s_ntrue.p, S.s_childA.p, S.s_childB.p, S.flag.p, S.fscan.p, S.orig, S.final_order.p, S.map.p, S.b_orig[pp].p);
+    hipLaunchKernelGGL(k_partition, dim3(S.coarse.n), dim3(AI_BLOCK), 0, st, S.coarse.d.p, S.seg_start.p, S.s_gstart.p, S.s_split.p, S.s_ntrue.p,
+                       S.s_childA.p, S.s_childB.p, S.flag.p, S.fscan.p, S.orig, S.final_order.p, S.map.p, S.b_orig[pp].p);
     AI_KERNEL_CHECK();
+    int32_t* parent_next = (S.parent == S.b_parent[0].p) ? S.b_parent[1].p : S.b_parent[0].p;
     if (cstart > 0) {
+      const unsigned gr = (unsigned)((S.na + AI_BLOCK - 1) / AI_BLOCK);
       const unsigned ge = (unsigned)(((int64_t)S.na * AI_LPR + AI_BLOCK - 1) / AI_BLOCK);
+      if (any_carry) {
+        hipLaunchKernelGGL(k_carry_parent, dim3(gr), dim3(AI_BLOCK), 0, st, (const int32_t*)S.parent, (const int32_t*)S.map.p, S.na, parent_next);
+        AI_KERNEL_CHECK();
+      }
       AI_HIP(hipMemsetAsync(S.newcnt.p, 0, (size_t)(cstart + 1) * sizeof(int32_t), st));
       hipLaunchKernelGGL(k_rebuild_count, dim3(ge), dim3(AI_BLOCK), 0, st, S.rowptr, S.col, S.flag.p, S.map.p, S.na, S.newcnt.p);
       AI_KERNEL_CHECK();
@@ -1526,6 +1718,7 @@ extern "C" int ai_ncut(ai_ctx* ctx, const ai_csr* csr, int64_t num_points_orig, 
     S.col = S.b_col[pp].p;
     S.wraw = S.b_wraw[pp].p;
     S.orig = S.b_orig[pp].p;
+    S.parent = parent_next;
     S.pp ^= 1;
     S.na = cstart;
     S.segs.swap(next);
@@ -1582,9 +1775,9 @@ extern "C" int ai_fiedler(ai_ctx* ctx, const ai_csr* csr, const ai_ncut_opts* op
   AI_TRY(S.lanczos(&theta, &it, &rs));
   hipStream_t st = ctx->stream;
   // unit norm + sign convention, then back to the caller's order
-  hipLaunchKernelGGL(k_minmax, dim3(S.ntask), dim3(AI_BLOCK), 0, st, S.task_seg.p, S.task_lo.p, S.task_hi.p, S.s_mode.p, S.ev.p, S.orig, S.pmm.p);
+  hipLaunchKernelGGL(k_minmax, dim3(S.coarse.n), dim3(AI_BLOCK), 0, st, S.coarse.d.p, S.ev.p, S.orig, S.pmm.p);
   AI_KERNEL_CHECK();
-  hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(64), 0, st, S.task0.p, S.s_mode.p, S.pmm.p, 1, 0, S.s_scale.p, S.s_nosplit.p, S.s_thr.p);
+  hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(64), 0, st, S.coarse.d_seg0.p, S.pmm.p, 1, 0, S.s_scale.p, S.s_nosplit.p, S.s_thr.p);
   AI_KERNEL_CHECK();
   double sc = 1.0;
   AI_HIP(hipMemcpyAsync(&sc, S.s_scale.p, sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1616,13 +1809,13 @@ extern "C" int ai_sweep(ai_ctx* ctx, const ai_csr* csr, const double* ev, double
   hipLaunchKernelGGL(k_gather_d, dim3((n + AI_BLOCK - 1) / AI_BLOCK), dim3(AI_BLOCK), 0, st, (const double*)S.Y.p, S.orig, n, S.ev.p);
   AI_KERNEL_CHECK();
   std::vector<int32_t> sp, nt;
-  AI_TRY(S.sweep(INFINITY, 1, sp, nt));
+  std::vector<double> mcs;
+  AI_TRY(S.sweep(INFINITY, 1, sp, nt, mcs));
   AI_HIP(hipMemcpyAsync(costs, S.s_costs.p, AI_NUM_CUTS * sizeof(double), hipMemcpyDeviceToHost, st));
   int32_t ks = 0;
-  double mc = 0.0;
   AI_HIP(hipMemcpyAsync(&ks, S.s_kstar.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-  AI_HIP(hipMemcpyAsync(&mc, S.s_mcut.p, sizeof(double), hipMemcpyDeviceToHost, st));
   AI_HIP(hipStreamSynchronize(st));
+  const double mc = mcs[0];
   if (mcut) *mcut = mc;
   if (mask_out) {
     DevBuf<uint8_t> dm;
@@ -1682,32 +1875,21 @@ extern "C" int ai_bench_spmv(ai_ctx* ctx, const ai_csr* csr, int32_t reps, doubl
   hipStream_t st = ctx->stream;
   S.slab_stride = (size_t)S.na;
   AI_TRY(S.ensure_vec(0));
-  AI_HIP(hipMemsetAsync(S.s_frozen.p, 0, sizeof(int32_t), st));
-  AI_HIP(hipMemsetAsync(S.s_g.p, 0, sizeof(double), st));
-  const double one = 1.0;
-  AI_HIP(hipMemcpyAsync(S.s_rb.p, &one, sizeof(double), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(k_lz_init, dim3(S.ntask), dim3(AI_BLOCK), 0, st, S.task_seg.p, S.task_lo.p, S.task_hi.p, S.s_mode.p, S.orig, S.u1.p,
-                     S.vec(0), S.pB.p);
+  hipLaunchKernelGGL(k_lz_init, dim3(S.coarse.n), dim3(AI_BLOCK), 0, st, S.coarse.d.p, S.cactive.p, S.orig, S.u1.p, S.vec(0), S.pB[0].p);
   AI_KERNEL_CHECK();
-  auto launch = [&]() {
-    hipLaunchKernelGGL(k_lz_spmv, dim3(S.ntask), dim3(AI_BLOCK), 0, st, S.task_seg.p, S.task_lo.p, S.task_hi.p, S.ntask, S.s_mode.p,
-                       S.s_frozen.p, S.s_g.p, S.s_rb.p, S.rowptr, S.col, S.wm.p, S.sinv2.p, S.u1.p, (const double*)S.vec(0), S.Y.p, S.pA.p);
-  };
-  for (int i = 0; i < 3; ++i) launch();
-  AI_KERNEL_CHECK();
+  for (int i = 0; i < 3; ++i) AI_TRY(S.launch_spmv(0));
   AI_HIP(hipEventRecord(ctx->ev[0], st));
-  for (int i = 0; i < reps; ++i) launch();
+  for (int i = 0; i < reps; ++i) AI_TRY(S.launch_spmv(0));
   AI_HIP(hipEventRecord(ctx->ev[1], st));
-  AI_KERNEL_CHECK();
   AI_HIP(hipStreamSynchronize(st));
   float ms = 0.f;
   AI_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
   *avg_ms = (double)ms / reps;
   if (bytes_per_launch) {
     // E (4 B index + 8 B value) + (N + 1) 4 B row pointers +
-    // N x 8 B x {R_j read, sinv2, u1, Y written}
+    // N x 8 B x {R_j read, sinv2 read, z written}
     const double N = (double)csr->n, E = (double)csr->nnz;
-    *bytes_per_launch = E * 12.0 + (N + 1.0) * 4.0 + N * 8.0 * 4.0;
+    *bytes_per_launch = E * 12.0 + (N + 1.0) * 4.0 + N * 8.0 * 3.0;
   }
   return AI_OK;
 }

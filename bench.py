@@ -39,9 +39,9 @@ def spmv_bytes(rows: int, nnz: int, launches: int) -> float:
     """Algorithmic bytes of the fused SpMV launches.
 
     Per stored entry: 4 B column index + 8 B scaled weight.  Per row: 4 B row pointer, and
-    8 B each for R_j (read once: the gathers re-use it from cache), sinv2, u1 and the y written.
+    8 B each for R_j (read once: the gathers re-use it from cache), sinv2 and the z written.
     """
-    return nnz * 12.0 + rows * (4.0 + 4 * 8.0) + launches * 4.0
+    return nnz * 12.0 + rows * (4.0 + 3 * 8.0) + launches * 4.0
 
 
 def cpu_baseline(seconds_budget: float = 30.0):
