@@ -40,7 +40,11 @@ extern "C" int ai_ctx_create(int device, ai_ctx** out) {
   c->num_cu = prop.multiProcessorCount;
   AI_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   for (int i = 0; i < 8; ++i) AI_HIP(hipEventCreate(&c->ev[i]));
-  for (int i = 0; i < AI_CHECK_DEPTH; ++i) AI_HIP(hipEventCreateWithFlags(&c->chk_ev[i], hipEventDisableTiming));
+  AI_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+  for (int i = 0; i < AI_CHECK_DEPTH; ++i) {
+    AI_HIP(hipEventCreateWithFlags(&c->chk_ev[i], hipEventDisableTiming));
+    AI_HIP(hipEventCreateWithFlags(&c->chk_ev1[i], hipEventDisableTiming));
+  }
   AI_HIP(hipHostMalloc((void**)&c->pinned, AI_PINNED_INTS * sizeof(int32_t), hipHostMallocDefault));
   *out = c;
   return AI_OK;
@@ -51,7 +55,12 @@ extern "C" int ai_ctx_destroy(ai_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (int i = 0; i < 8; ++i) (void)hipEventDestroy(ctx->ev[i]);
-  for (int i = 0; i < AI_CHECK_DEPTH; ++i) (void)hipEventDestroy(ctx->chk_ev[i]);
+  (void)hipStreamSynchronize(ctx->side);
+  for (int i = 0; i < AI_CHECK_DEPTH; ++i) {
+    (void)hipEventDestroy(ctx->chk_ev[i]);
+    (void)hipEventDestroy(ctx->chk_ev1[i]);
+  }
+  (void)hipStreamDestroy(ctx->side);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;

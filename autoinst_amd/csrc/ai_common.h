@@ -37,7 +37,9 @@ struct ai_ctx {
   hipEvent_t ev[8];
   int num_cu;
   int32_t* pinned;          // AI_PINNED_INTS host-pinned ints: results of in-flight convergence checks
-  hipEvent_t chk_ev[AI_CHECK_DEPTH];  // one event per in-flight check
+  hipEvent_t chk_ev[AI_CHECK_DEPTH];   // one event per in-flight check (recorded on `side`)
+  hipEvent_t chk_ev1[AI_CHECK_DEPTH];  // main stream -> side stream hand-off of a check's inputs
+  hipStream_t side;                    // convergence checks run here, beside the Lanczos steps
 };
 
 struct ai_csr {

@@ -19,6 +19,7 @@
 //     sums by two-stage fixed-order reductions (no float atomics: reproducible run to run).
 // tests/gpu_model.py is the NumPy model of this algorithm.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -512,14 +513,33 @@ __device__ __forceinline__ int sturm_lt(const double* a, const double* bb, int m
   return cnt;
 }
 
-// Convergence check after step j (m = j + 1 rows of T), one wave per running segment:
-// b_m from the partials of R_m; top eigenvalue of T_m by 64-way multisection; |s_m| by the
-// recurrence from the bottom row upwards (the growing, hence stable, direction);
-// residual = b_m |s_m|.  Freezes the segment when residual <= tol or T has reached the
-// segment's dimension / the step cap.  slot[0] counts the segments still running;
-// work[] accumulates rows and stored entries the SpMV kernel processed since the last check.
+// b_m = ||R_m - g_m u1|| per running segment from the update kernel's partials (main stream: the
+// partials are overwritten two steps later, the check itself runs on the side stream)
+__global__ __launch_bounds__(64) void k_lz_bnew(const TaskRange* __restrict__ seg_range, const int32_t* __restrict__ mode,
+                                                const int32_t* __restrict__ frozen, const double2* __restrict__ pB,
+                                                double* __restrict__ bnew_out) {
+  const int s = blockIdx.x;
+  if (mode[s] != 0 || frozen[s]) return;
+  const TaskRange rg = seg_range[s];
+  double nn = 0.0, gg = 0.0;
+  for (int t = rg.z + threadIdx.x; t < rg.w; t += 64) {
+    const double2 v = pB[t];
+    nn += v.x;
+    gg += v.y;
+  }
+  nn = ai_wave_sum(nn);
+  gg = ai_wave_sum(gg);
+  if (threadIdx.x == 0) bnew_out[s] = sqrt(fmax(nn - gg * gg, 0.0));
+}
+
+// Convergence check after step j (m = j + 1 rows of T), one wave per running segment, on the side
+// stream: top eigenvalue of T_m by 64-way multisection; |s_m| by the recurrence from the bottom
+// row upwards (the growing, hence stable, direction); residual = b_m |s_m|.  Freezes the segment
+// when residual <= tol or T has reached the segment's dimension / the step cap.  slot[0] counts
+// the segments still running; work[] accumulates rows and stored entries the SpMV kernel
+// processed since the last check.  Reads only history entries [0, m), which later steps never touch.
 __global__ __launch_bounds__(64) void k_lz_check(const int32_t* __restrict__ seg_start, const TaskRange* __restrict__ seg_range,
-                                                 const int32_t* __restrict__ mode, LzSeg L, const double2* __restrict__ pB, int m,
+                                                 const int32_t* __restrict__ mode, LzSeg L, const double* __restrict__ bnew_in, int m,
                                                  double tol, int max_iter, int steps_since, const int32_t* __restrict__ rowptr,
                                                  double* __restrict__ theta_out, double* __restrict__ resid_out,
                                                  int32_t* __restrict__ slot, unsigned long long* __restrict__ work) {
@@ -533,15 +553,7 @@ __global__ __launch_bounds__(64) void k_lz_check(const int32_t* __restrict__ seg
     atomicAdd(&work[0], (unsigned long long)ns * (unsigned long long)steps_since);
     atomicAdd(&work[1], (unsigned long long)(rowptr[seg_start[s + 1]] - rowptr[seg_start[s]]) * (unsigned long long)steps_since);
   }
-  double nn = 0.0, gg = 0.0;
-  for (int t = rg.z + lane; t < rg.w; t += 64) {
-    const double2 v = pB[t];
-    nn += v.x;
-    gg += v.y;
-  }
-  nn = ai_wave_sum(nn);
-  gg = ai_wave_sum(gg);
-  const double bnew = sqrt(fmax(nn - gg * gg, 0.0));
+  const double bnew = bnew_in[s];
   const double* bh = L.b_hist + (size_t)s * (L.mcap + 1);
   const double* ah = L.alpha_hist + (size_t)s * L.mcap;
   // T_m into LDS: a[0..m), b^2[0..m) (b^2[0] unused)
@@ -1121,7 +1133,8 @@ class Solver {
   DevBuf<int32_t> rcnt, rc, ex, flag, fscan, map, newcnt, scantmp, final_order;
   DevBuf<uint8_t> side, bin;
   // tasks
-  TaskList fine, coarse;
+  TaskList fine, coarse;  // every active row
+  TaskList lzf, lzc;      // rows of the Lanczos-mode segments only (grids of the step kernels)
   std::vector<TaskRange> h_cranges, h_segrange;
   DevBuf<TaskRange> cranges, segrange;
   std::vector<int32_t> h_seg_start;
@@ -1133,7 +1146,7 @@ class Solver {
   DevBuf<int32_t> s_mode, s_needcc, s_frozen, s_m, s_ncomp, s_nosplit, s_kstar, s_split, s_ntrue, s_gstart, s_childA, s_childB, slots;
   DevBuf<double> s_theta, s_resid, s_vol, s_volA, s_volB, s_scale, s_thr, s_costs, s_mcut, s_cu;
   // Lanczos history + vectors
-  DevBuf<double> alpha_hist, b_hist, g_hist, coef;
+  DevBuf<double> alpha_hist, b_hist, g_hist, coef, bnew_buf;
   int mcap = 0;
   std::vector<double*> slabs;
   size_t slab_stride = 0;
@@ -1233,13 +1246,14 @@ class Solver {
     return AI_OK;
   }
 
-  void make_tasks(TaskList& tl, int rows_per_task) {
+  void make_tasks(TaskList& tl, int rows_per_task, bool lanczos_only = false) {
     const int S_ = S();
     tl.rows_per_task = rows_per_task;
     tl.h.clear();
     tl.h_seg0.assign(S_ + 1, 0);
     for (int s = 0; s < S_; ++s) {
       tl.h_seg0[s] = (int32_t)tl.h.size();
+      if (lanczos_only && segs[s].mode != 0) continue;
       bool first = true;
       for (int lo = segs[s].start; lo < segs[s].start + segs[s].n; lo += rows_per_task) {
         Task t;
@@ -1262,38 +1276,25 @@ class Solver {
     make_tasks(coarse, AI_COARSE_ROWS);
     h_seg_start.assign(S_ + 1, 0);
     std::vector<int32_t> h_gstart(S_ + 1, 0), h_needcc(S_ + 1, 0);
-    h_segrange.assign(S_ + 1, TaskRange{0, 0, 0, 0});
     for (int s = 0; s < S_; ++s) {
       h_seg_start[s] = segs[s].start;
       h_gstart[s] = segs[s].gstart;
       h_needcc[s] = segs[s].need_cc;
-      h_segrange[s] = TaskRange{fine.h_seg0[s], fine.h_seg0[s + 1], coarse.h_seg0[s], coarse.h_seg0[s + 1]};
     }
     h_seg_start[S_] = S_ ? segs[S_ - 1].start + segs[S_ - 1].n : 0;
-    h_cranges.resize(coarse.n);
-    for (int t = 0; t < coarse.n; ++t) h_cranges[t] = h_segrange[coarse.h[t].z];
     AI_TRY(alloc_segs(S_));
     AI_TRY(fine.d.ensure(fine.n + 1));
     AI_TRY(fine.d_seg0.ensure(S_ + 1));
     AI_TRY(coarse.d.ensure(coarse.n + 1));
     AI_TRY(coarse.d_seg0.ensure(S_ + 1));
-    AI_TRY(cranges.ensure(coarse.n + 1));
-    AI_TRY(segrange.ensure(S_ + 1));
     AI_TRY(seg_start.ensure(S_ + 1));
-    AI_TRY(factive.ensure(fine.n + 1));
-    AI_TRY(cactive.ensure(coarse.n + 1));
     AI_TRY(pvol.ensure(fine.n + 1));
-    AI_TRY(pA.ensure(fine.n + 1));
     AI_TRY(psweep.ensure((size_t)(fine.n + 1) * AI_SWEEP_VALS));
-    AI_TRY(pB[0].ensure(coarse.n + 1));
-    AI_TRY(pB[1].ensure(coarse.n + 1));
     AI_TRY(pvolA.ensure(coarse.n + 1));
     AI_TRY(pvolB.ensure(coarse.n + 1));
     AI_TRY(pmm.ensure(coarse.n + 1));
     AI_HIP(hipMemcpyAsync(fine.d.p, fine.h.data(), fine.n * sizeof(Task), hipMemcpyHostToDevice, st));
     AI_HIP(hipMemcpyAsync(coarse.d.p, coarse.h.data(), coarse.n * sizeof(Task), hipMemcpyHostToDevice, st));
-    AI_HIP(hipMemcpyAsync(cranges.p, h_cranges.data(), coarse.n * sizeof(TaskRange), hipMemcpyHostToDevice, st));
-    AI_HIP(hipMemcpyAsync(segrange.p, h_segrange.data(), (S_ + 1) * sizeof(TaskRange), hipMemcpyHostToDevice, st));
     AI_HIP(hipMemcpyAsync(fine.d_seg0.p, fine.h_seg0.data(), (S_ + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
     AI_HIP(hipMemcpyAsync(coarse.d_seg0.p, coarse.h_seg0.data(), (S_ + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
     AI_HIP(hipMemcpyAsync(seg_start.p, h_seg_start.data(), (S_ + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
@@ -1330,16 +1331,39 @@ class Solver {
       AI_HIP(hipMemcpyAsync(ncomp.data(), s_ncomp.p, (size_t)S_ * sizeof(int32_t), hipMemcpyDeviceToHost, st));
       AI_HIP(hipStreamSynchronize(st));
     }
-    std::vector<int32_t> mode(S_), fa(fine.n), ca(coarse.n);
+    std::vector<int32_t> mode(S_);
     for (int s = 0; s < S_; ++s) {
       segs[s].mode = (ncomp[s] > 1) ? 1 : 0;
       mode[s] = segs[s].mode;
     }
-    for (int t = 0; t < fine.n; ++t) fa[t] = (mode[fine.h[t].z] == 0) ? 1 : 0;
-    for (int t = 0; t < coarse.n; ++t) ca[t] = (mode[coarse.h[t].z] == 0) ? 1 : 0;
+    // step kernels run on the Lanczos-mode segments only: their own (compact) task lists, so that
+    // a frontier with few connected segments launches few blocks and the XCD remap still spreads
+    // them over the whole chip
+    make_tasks(lzf, AI_FINE_ROWS, true);
+    make_tasks(lzc, AI_COARSE_ROWS, true);
+    h_segrange.assign(S_ + 1, TaskRange{0, 0, 0, 0});
+    for (int s = 0; s < S_; ++s) h_segrange[s] = TaskRange{lzf.h_seg0[s], lzf.h_seg0[s + 1], lzc.h_seg0[s], lzc.h_seg0[s + 1]};
+    h_cranges.resize(lzc.n);
+    for (int t = 0; t < lzc.n; ++t) h_cranges[t] = h_segrange[lzc.h[t].z];
+    std::vector<int32_t> ones((size_t)std::max(lzf.n, lzc.n) + 1, 1);
+    AI_TRY(lzf.d.ensure(lzf.n + 1));
+    AI_TRY(lzc.d.ensure(lzc.n + 1));
+    AI_TRY(cranges.ensure(lzc.n + 1));
+    AI_TRY(segrange.ensure(S_ + 1));
+    AI_TRY(factive.ensure(lzf.n + 1));
+    AI_TRY(cactive.ensure(lzc.n + 1));
+    AI_TRY(pA.ensure(lzf.n + 1));
+    AI_TRY(pB[0].ensure(lzc.n + 1));
+    AI_TRY(pB[1].ensure(lzc.n + 1));
     AI_HIP(hipMemcpyAsync(s_mode.p, mode.data(), (size_t)S_ * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    AI_HIP(hipMemcpyAsync(factive.p, fa.data(), (size_t)fine.n * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    AI_HIP(hipMemcpyAsync(cactive.p, ca.data(), (size_t)coarse.n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    AI_HIP(hipMemcpyAsync(segrange.p, h_segrange.data(), (size_t)(S_ + 1) * sizeof(TaskRange), hipMemcpyHostToDevice, st));
+    if (lzf.n) {
+      AI_HIP(hipMemcpyAsync(lzf.d.p, lzf.h.data(), (size_t)lzf.n * sizeof(Task), hipMemcpyHostToDevice, st));
+      AI_HIP(hipMemcpyAsync(lzc.d.p, lzc.h.data(), (size_t)lzc.n * sizeof(Task), hipMemcpyHostToDevice, st));
+      AI_HIP(hipMemcpyAsync(cranges.p, h_cranges.data(), (size_t)lzc.n * sizeof(TaskRange), hipMemcpyHostToDevice, st));
+      AI_HIP(hipMemcpyAsync(factive.p, ones.data(), (size_t)lzf.n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+      AI_HIP(hipMemcpyAsync(cactive.p, ones.data(), (size_t)lzc.n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    }
     AI_HIP(hipStreamSynchronize(st));
     return AI_OK;
   }
@@ -1385,7 +1409,7 @@ class Solver {
   }
 
   int launch_spmv(int j) {
-    hipLaunchKernelGGL(k_lz_spmv, dim3(fine.n), dim3(AI_BLOCK), 0, st, fine.d.p, factive.p, fine.n, rowptr, col, wm.p, sinv2.p,
+    hipLaunchKernelGGL(k_lz_spmv, dim3(lzf.n), dim3(AI_BLOCK), 0, st, lzf.d.p, factive.p, lzf.n, rowptr, col, wm.p, sinv2.p,
                        (const double*)vec(j), Y.p, pA.p);
     AI_KERNEL_CHECK();
     return AI_OK;
@@ -1407,10 +1431,15 @@ class Solver {
     if (nl == 0) return AI_OK;
     stats.lanczos_solves += nl;
     mcap = std::max(1, std::min(opt.max_iter, max_n - 1));
-    AI_TRY(alpha_hist.ensure((size_t)S_ * mcap));
-    AI_TRY(b_hist.ensure((size_t)S_ * (mcap + 1)));
-    AI_TRY(g_hist.ensure((size_t)S_ * (mcap + 1)));
-    AI_TRY(coef.ensure((size_t)S_ * mcap));
+    {
+      // sized once for the usual frontier (children are > 1 % of the chunk, so <= ~100 segments)
+      const size_t scap = (size_t)std::max(S_, 128), mc = (size_t)std::max(mcap, opt.max_iter);
+      AI_TRY(alpha_hist.ensure(scap * mc));
+      AI_TRY(b_hist.ensure(scap * (mc + 1)));
+      AI_TRY(g_hist.ensure(scap * (mc + 1)));
+      AI_TRY(coef.ensure(scap * mc));
+      AI_TRY(bnew_buf.ensure((size_t)AI_CHECK_DEPTH * (scap + 1)));
+    }
     // vectors live in slabs whose stride is the row count of the first level that needs them
     // (levels only shrink)
     if (slab_stride == 0) slab_stride = (size_t)na;
@@ -1422,7 +1451,7 @@ class Solver {
     AI_TRY(ensure_vec(0));
     AI_TRY(ensure_vec(1));
     AI_HIP(hipEventRecord(ctx->ev[0], st));
-    hipLaunchKernelGGL(k_lz_init, dim3(coarse.n), dim3(AI_BLOCK), 0, st, coarse.d.p, cactive.p, orig, u1.p, vec(0), pB[0].p);
+    hipLaunchKernelGGL(k_lz_init, dim3(lzc.n), dim3(AI_BLOCK), 0, st, lzc.d.p, cactive.p, orig, u1.p, vec(0), pB[0].p);
     AI_KERNEL_CHECK();
     const bool dense_checks = (min_n <= 512);
     int next_check = dense_checks ? 1 : opt.check_every;
@@ -1465,7 +1494,7 @@ class Solver {
       }
       AI_TRY(launch_spmv(j));
       if (time_spmv) AI_HIP(hipEventRecord(evpool[2 * j + 1], st));
-      hipLaunchKernelGGL(k_lz_update, dim3(coarse.n), dim3(AI_BLOCK), 0, st, coarse.d.p, cranges.p, L, j, (const double*)pA.p,
+      hipLaunchKernelGGL(k_lz_update, dim3(lzc.n), dim3(AI_BLOCK), 0, st, lzc.d.p, cranges.p, L, j, (const double*)pA.p,
                          (const double2*)pB[j & 1].p, pB[(j + 1) & 1].p, u1.p, (const double*)Y.p, (const double*)vec(j),
                          (const double*)vec(j > 0 ? j - 1 : 0), vec(j + 1));
       AI_KERNEL_CHECK();
@@ -1475,12 +1504,18 @@ class Solver {
       if (check && nchecks < AI_MAX_CHECKS) {
         // at most AI_CHECK_DEPTH checks in flight (their events and pinned slots are recycled)
         if (pending.size() - phead >= (size_t)AI_CHECK_DEPTH - 1) AI_TRY(reap(true));
-        hipLaunchKernelGGL(k_lz_check, dim3(S_), dim3(64), (size_t)2 * m * sizeof(double), st, seg_start.p, segrange.p, s_mode.p, L,
-                           (const double2*)pB[(j + 1) & 1].p, m, opt.tol, opt.max_iter, m - last_check_m, rowptr, s_theta.p, s_resid.p,
+        const int cd = nchecks % AI_CHECK_DEPTH;
+        double* bn = bnew_buf.p + (size_t)cd * (S_ + 1);
+        hipLaunchKernelGGL(k_lz_bnew, dim3(S_), dim3(64), 0, st, segrange.p, s_mode.p, s_frozen.p, (const double2*)pB[(j + 1) & 1].p, bn);
+        AI_KERNEL_CHECK();
+        AI_HIP(hipEventRecord(ctx->chk_ev1[cd], st));
+        AI_HIP(hipStreamWaitEvent(ctx->side, ctx->chk_ev1[cd], 0));
+        hipLaunchKernelGGL(k_lz_check, dim3(S_), dim3(64), (size_t)2 * m * sizeof(double), ctx->side, seg_start.p, segrange.p, s_mode.p, L,
+                           (const double*)bn, m, opt.tol, opt.max_iter, m - last_check_m, rowptr, s_theta.p, s_resid.p,
                            slots.p + nchecks, work.p);
         AI_KERNEL_CHECK();
-        AI_HIP(hipMemcpyAsync(&ctx->pinned[nchecks % AI_PINNED_INTS], slots.p + nchecks, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        AI_HIP(hipEventRecord(ctx->chk_ev[nchecks % AI_CHECK_DEPTH], st));
+        AI_HIP(hipMemcpyAsync(&ctx->pinned[nchecks % AI_PINNED_INTS], slots.p + nchecks, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->side));
+        AI_HIP(hipEventRecord(ctx->chk_ev[cd], ctx->side));
         pending.push_back(Pending{nchecks, m});
         ++nchecks;
         last_check_m = m;
@@ -1492,6 +1527,10 @@ class Solver {
     }
     while (phead < pending.size()) AI_TRY(reap(true));
     stats.lanczos_steps += steps;
+    if (getenv("AI_NCUT_DEBUG")) {
+      fprintf(stderr, "[ai_ncut] level %lld: segments %d (lanczos %d, rows %d..%d), active rows %d, steps %d, checks %d\n",
+              (long long)stats.levels, S_, nl, min_n, max_n, na, steps, nchecks);
+    }
     if (time_spmv) {
       AI_HIP(hipStreamSynchronize(st));
       for (int j = 0; j < steps; ++j) {
@@ -1506,9 +1545,13 @@ class Solver {
         h_cu(S_, 0.0), h_resid(S_, 0.0);
     AI_HIP(hipMemcpyAsync(h_m.data(), s_m.p, (size_t)S_ * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     AI_HIP(hipMemcpyAsync(h_frozen.data(), s_frozen.p, (size_t)S_ * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    AI_HIP(hipMemcpyAsync(h_a.data(), alpha_hist.p, h_a.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-    AI_HIP(hipMemcpyAsync(h_b.data(), b_hist.p, h_b.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-    AI_HIP(hipMemcpyAsync(h_g.data(), g_hist.p, h_g.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    {
+      // only the columns the steps have filled
+      const size_t wa = (size_t)std::min(steps, mcap) * sizeof(double), wb = (size_t)std::min(steps + 1, mcap + 1) * sizeof(double);
+      AI_HIP(hipMemcpy2DAsync(h_a.data(), (size_t)mcap * sizeof(double), alpha_hist.p, (size_t)mcap * sizeof(double), wa, S_, hipMemcpyDeviceToHost, st));
+      AI_HIP(hipMemcpy2DAsync(h_b.data(), (size_t)(mcap + 1) * sizeof(double), b_hist.p, (size_t)(mcap + 1) * sizeof(double), wb, S_, hipMemcpyDeviceToHost, st));
+      AI_HIP(hipMemcpy2DAsync(h_g.data(), (size_t)(mcap + 1) * sizeof(double), g_hist.p, (size_t)(mcap + 1) * sizeof(double), wb, S_, hipMemcpyDeviceToHost, st));
+    }
     AI_HIP(hipMemcpyAsync(h_resid.data(), s_resid.p, (size_t)S_ * sizeof(double), hipMemcpyDeviceToHost, st));
     AI_HIP(hipStreamSynchronize(st));
     int max_m = 0;
@@ -1549,10 +1592,11 @@ class Solver {
       }
     }
     AI_HIP(hipMemcpyAsync(s_m.p, h_m.data(), (size_t)S_ * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    AI_HIP(hipMemcpyAsync(coef.p, h_coef.data(), h_coef.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    AI_HIP(hipMemcpy2DAsync(coef.p, (size_t)mcap * sizeof(double), h_coef.data(), (size_t)mcap * sizeof(double),
+                            (size_t)std::max(max_m, 1) * sizeof(double), S_, hipMemcpyHostToDevice, st));
     AI_HIP(hipMemcpyAsync(s_cu.p, h_cu.data(), (size_t)S_ * sizeof(double), hipMemcpyHostToDevice, st));
     for (int j0 = 0; j0 < max_m; j0 += AI_SLAB_VECS) {
-      hipLaunchKernelGGL(k_ritz, dim3(coarse.n), dim3(AI_BLOCK), 0, st, coarse.d.p, s_mode.p, s_m.p, coef.p, mcap, s_cu.p, u1.p,
+      hipLaunchKernelGGL(k_ritz, dim3(lzc.n), dim3(AI_BLOCK), 0, st, lzc.d.p, s_mode.p, s_m.p, coef.p, mcap, s_cu.p, u1.p,
                          (const double*)slabs[(size_t)j0 / AI_SLAB_VECS], slab_stride, j0, AI_SLAB_VECS, j0 == 0 ? 1 : 0, ev.p);
       AI_KERNEL_CHECK();
     }
@@ -1875,7 +1919,7 @@ extern "C" int ai_bench_spmv(ai_ctx* ctx, const ai_csr* csr, int32_t reps, doubl
   hipStream_t st = ctx->stream;
   S.slab_stride = (size_t)S.na;
   AI_TRY(S.ensure_vec(0));
-  hipLaunchKernelGGL(k_lz_init, dim3(S.coarse.n), dim3(AI_BLOCK), 0, st, S.coarse.d.p, S.cactive.p, S.orig, S.u1.p, S.vec(0), S.pB[0].p);
+  hipLaunchKernelGGL(k_lz_init, dim3(S.lzc.n), dim3(AI_BLOCK), 0, st, S.lzc.d.p, S.cactive.p, S.orig, S.u1.p, S.vec(0), S.pB[0].p);
   AI_KERNEL_CHECK();
   for (int i = 0; i < 3; ++i) AI_TRY(S.launch_spmv(0));
   AI_HIP(hipEventRecord(ctx->ev[0], st));
