@@ -26,6 +26,8 @@
 #include <chrono>
 #include <set>
 
+#include <hip/hip_ext.h>
+
 #include "ai_common.h"
 
 #define AI_FINE_ROWS 64      // rows per block in the 16-lanes-per-row kernels (4 rows in flight per lane group)
@@ -1408,9 +1410,15 @@ class Solver {
     return AI_OK;
   }
 
-  int launch_spmv(int j) {
-    hipLaunchKernelGGL(k_lz_spmv, dim3(lzf.n), dim3(AI_BLOCK), 0, st, lzf.d.p, factive.p, lzf.n, rowptr, col, wm.p, sinv2.p,
-                       (const double*)vec(j), Y.p, pA.p);
+  // e0 / e1 (optional): HIP events that receive this dispatch's own start / stop timestamps
+  int launch_spmv(int j, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+    if (e0) {
+      hipExtLaunchKernelGGL(k_lz_spmv, dim3(lzf.n), dim3(AI_BLOCK), 0, st, e0, e1, 0, (const Task*)lzf.d.p, (const int32_t*)factive.p, lzf.n,
+                            rowptr, col, (const double*)wm.p, (const double*)sinv2.p, (const double*)vec(j), Y.p, pA.p);
+    } else {
+      hipLaunchKernelGGL(k_lz_spmv, dim3(lzf.n), dim3(AI_BLOCK), 0, st, lzf.d.p, factive.p, lzf.n, rowptr, col, wm.p, sinv2.p,
+                         (const double*)vec(j), Y.p, pA.p);
+    }
     AI_KERNEL_CHECK();
     return AI_OK;
   }
@@ -1490,10 +1498,10 @@ class Solver {
           AI_HIP(hipEventCreate(&e));
           evpool.push_back(e);
         }
-        AI_HIP(hipEventRecord(evpool[2 * j], st));
+        AI_TRY(launch_spmv(j, evpool[2 * j], evpool[2 * j + 1]));
+      } else {
+        AI_TRY(launch_spmv(j));
       }
-      AI_TRY(launch_spmv(j));
-      if (time_spmv) AI_HIP(hipEventRecord(evpool[2 * j + 1], st));
       hipLaunchKernelGGL(k_lz_update, dim3(lzc.n), dim3(AI_BLOCK), 0, st, lzc.d.p, cranges.p, L, j, (const double*)pA.p,
                          (const double2*)pB[j & 1].p, pB[(j + 1) & 1].p, u1.p, (const double*)Y.p, (const double*)vec(j),
                          (const double*)vec(j > 0 ? j - 1 : 0), vec(j + 1));
