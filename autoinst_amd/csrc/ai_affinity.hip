@@ -274,6 +274,7 @@ extern "C" int ai_affinity_build(ai_ctx* ctx, const double* xyz, int64_t n, cons
   AI_HIP(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   *out = nullptr;
+  ArenaScope arena_scope(&ctx->arena);  // scratch comes from the context's arena; the graph itself is hipMalloc'd
 
   DevBuf<double> own_xyz, own_tarl, own_dino;
   const double *d_xyz, *d_tarl, *d_dino;

@@ -14,6 +14,37 @@ void ai_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* ai_last_error(void) { return g_err; }
+
+// ----------------------------------------------------------------------------- arena
+static thread_local ai_arena* g_arena = nullptr;
+ai_arena* ai_current_arena() { return g_arena; }
+void ai_set_current_arena(ai_arena* a) { g_arena = a; }
+
+void* ai_arena::alloc(size_t bytes) {
+  bytes = (bytes + 255) & ~(size_t)255;
+  // first block, from the current one on, that still has room
+  for (size_t b = cur; b < blocks.size(); ++b) {
+    const size_t o = (b == cur) ? off : 0;
+    if (o + bytes <= blocks[b].cap) {
+      cur = b;
+      off = o + bytes;
+      return blocks[b].base + o;
+    }
+  }
+  Block nb;
+  nb.cap = bytes > min_block ? bytes : min_block;
+  if (hipMalloc((void**)&nb.base, nb.cap) != hipSuccess) return nullptr;
+  blocks.push_back(nb);
+  cur = blocks.size() - 1;
+  off = bytes;
+  return nb.base;
+}
+
+void ai_arena::release_all() {
+  for (auto& b : blocks) (void)hipFree(b.base);
+  blocks.clear();
+  cur = off = 0;
+}
 extern "C" int ai_version(void) { return 100; }
 
 extern "C" int ai_ctx_create(int device, ai_ctx** out) {
@@ -46,6 +77,7 @@ extern "C" int ai_ctx_create(int device, ai_ctx** out) {
     AI_HIP(hipEventCreateWithFlags(&c->chk_ev1[i], hipEventDisableTiming));
   }
   AI_HIP(hipHostMalloc((void**)&c->pinned, AI_PINNED_INTS * sizeof(int32_t), hipHostMallocDefault));
+  AI_HIP(hipHostMalloc((void**)&c->stage, AI_STAGE_BYTES, hipHostMallocDefault));
   *out = c;
   return AI_OK;
 }
@@ -62,6 +94,8 @@ extern "C" int ai_ctx_destroy(ai_ctx* ctx) {
   }
   (void)hipStreamDestroy(ctx->side);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->stage) (void)hipHostFree(ctx->stage);
+  ctx->arena.release_all();
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return AI_OK;
@@ -192,6 +226,7 @@ extern "C" int ai_csr_export(ai_ctx* ctx, const ai_csr* csr, int64_t* indptr, in
     }
     AI_HIP(hipStreamSynchronize(st));
   } else {
+    ArenaScope arena_scope(&ctx->arena);
     DevBuf<int32_t> len, optr, ocol, tmp;
     DevBuf<double> oval;
     AI_TRY(len.alloc(n + 1));

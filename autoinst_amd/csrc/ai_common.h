@@ -28,18 +28,52 @@ void ai_set_error(const char* fmt, ...);
 
 #define AI_KERNEL_CHECK() AI_HIP(hipGetLastError())
 
+// ----------------------------------------------------------------------------- workspace arena
+// Call-scoped device workspace: a grow-only list of large hipMalloc'd blocks owned by the context,
+// bump-allocated during one API call and rewound when the call ends.  After the first chunk no
+// call allocates or frees device memory (hipMalloc / hipFree cost ~0.1 ms each and stall the stream).
+struct ai_arena {
+  struct Block {
+    char* base;
+    size_t cap;
+  };
+  std::vector<Block> blocks;
+  size_t cur = 0, off = 0;
+  size_t min_block = (size_t)256 << 20;
+  void* alloc(size_t bytes);  // nullptr on out-of-memory
+  void rewind() { cur = 0, off = 0; }
+  void release_all();
+};
+ai_arena* ai_current_arena();             // arena of the API call running on this thread (or nullptr)
+void ai_set_current_arena(ai_arena* a);
+
+struct ArenaScope {
+  ai_arena* prev;
+  explicit ArenaScope(ai_arena* a) : prev(ai_current_arena()) {
+    if (a) a->rewind();
+    ai_set_current_arena(a);
+  }
+  ~ArenaScope() {
+    if (ai_current_arena()) ai_current_arena()->rewind();
+    ai_set_current_arena(prev);
+  }
+};
+
 // ----------------------------------------------------------------------------- handles
 #define AI_PINNED_INTS 4096
 #define AI_CHECK_DEPTH 16
+#define AI_STAGE_BYTES ((size_t)8 << 20)
 struct ai_ctx {
   int device;
   hipStream_t stream;
   hipEvent_t ev[8];
   int num_cu;
-  int32_t* pinned;          // AI_PINNED_INTS host-pinned ints: results of in-flight convergence checks
+  int32_t* pinned;                     // AI_PINNED_INTS host-pinned ints: results of in-flight convergence checks
   hipEvent_t chk_ev[AI_CHECK_DEPTH];   // one event per in-flight check (recorded on `side`)
   hipEvent_t chk_ev1[AI_CHECK_DEPTH];  // main stream -> side stream hand-off of a check's inputs
   hipStream_t side;                    // convergence checks run here, beside the Lanczos steps
+  ai_arena arena;                      // call-scoped device workspace, kept between calls
+  char* stage;                         // AI_STAGE_BYTES of pinned host memory for packed small uploads / downloads
 };
 
 struct ai_csr {
@@ -52,29 +86,42 @@ struct ai_csr {
   int device;
 };
 
-// Device buffer that frees itself (workspace of one call).
+// Device buffer of one API call: carved from the context's arena when one is active (then
+// release is a no-op and the memory is reclaimed when the call ends), else hipMalloc / hipFree.
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
   size_t count = 0;
+  bool owned = false;
   DevBuf() {}
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
   ~DevBuf() { release(); }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p && owned) (void)hipFree(p);
     p = nullptr;
     count = 0;
+    owned = false;
   }
   int alloc(size_t n) {
     release();
     if (n == 0) n = 1;
+    if (ai_arena* a = ai_current_arena()) {
+      p = (T*)a->alloc(n * sizeof(T));
+      if (!p) {
+        ai_set_error("device workspace of %zu bytes could not be allocated", n * sizeof(T));
+        return AI_ERR_OOM;
+      }
+      count = n;
+      return AI_OK;
+    }
     hipError_t e = hipMalloc((void**)&p, n * sizeof(T));
     if (e != hipSuccess) {
       p = nullptr;
       ai_set_error("hipMalloc of %zu bytes failed: %s", n * sizeof(T), hipGetErrorString(e));
       return AI_ERR_OOM;
     }
+    owned = true;
     count = n;
     return AI_OK;
   }

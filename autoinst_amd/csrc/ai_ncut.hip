@@ -1011,7 +1011,7 @@ static int sturm_lt_host(const double* a, const double* b, int m, double x) {
   return cnt;
 }
 
-static void tridiag_top(const double* a, const double* b, int m, double* theta_out, std::vector<double>& s) {
+static void tridiag_top(const double* a, const double* b, int m, const double* hint, double* theta_out, std::vector<double>& s) {
   s.assign(m, 0.0);
   if (m == 1) {
     *theta_out = a[0];
@@ -1027,6 +1027,13 @@ static void tridiag_top(const double* a, const double* b, int m, double* theta_o
   }
   lo -= 1e-14 * std::max(fabs(lo), 1.0);
   hi += 1e-14 * std::max(fabs(hi), 1.0);
+  if (hint) {
+    // the device check already located the eigenvalue: verify a tight bracket around it
+    const double w = 1e-13 * std::max(fabs(*hint), 1.0);
+    const double l2 = *hint - w, h2 = *hint + w;
+    if (l2 > lo && sturm_lt_host(a, b, m, l2) < m) lo = l2;
+    if (h2 < hi && sturm_lt_host(a, b, m, h2) == m) hi = h2;
+  }
   for (int it = 0; it < 200; ++it) {
     const double mid = 0.5 * (lo + hi);
     if (mid <= lo || mid >= hi) break;
@@ -1096,13 +1103,54 @@ static double now_ms() {
   return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
+template <typename T>
+struct Ptr {  // a device pointer into a larger blob (same `.p` spelling as DevBuf)
+  T* p = nullptr;
+};
+
 struct TaskList {
   int rows_per_task = 0;
   int n = 0;
   std::vector<Task> h;
   std::vector<int32_t> h_seg0;
-  DevBuf<Task> d;
-  DevBuf<int32_t> d_seg0;
+  Ptr<Task> d;
+  Ptr<int32_t> d_seg0;
+};
+
+// Several small host arrays -> the context's pinned staging buffer -> ONE async copy into one
+// device blob; the device pointers are handed out after the copy is queued.
+struct Pack {
+  char* stage;
+  size_t cap, off = 0;
+  struct Item {
+    void** dst;
+    size_t off;
+  };
+  std::vector<Item> items;
+  bool overflow = false;
+  Pack(char* stage_, size_t cap_) : stage(stage_), cap(cap_) {}
+  template <typename T>
+  void add(T** dst, const T* src, size_t count) {
+    off = (off + 63) & ~(size_t)63;
+    const size_t bytes = (count ? count : 1) * sizeof(T);
+    if (off + bytes > cap) {
+      overflow = true;
+      return;
+    }
+    if (count) memcpy(stage + off, src, count * sizeof(T));
+    items.push_back(Item{(void**)dst, off});
+    off += bytes;
+  }
+  int flush(DevBuf<char>& blob, hipStream_t st) {
+    if (overflow) {
+      ai_set_error("per-level task tables exceed the %zu-byte staging buffer (too many segments for this build)", cap);
+      return AI_ERR_INTERNAL;
+    }
+    AI_TRY(blob.ensure(off + 64));
+    AI_HIP(hipMemcpyAsync(blob.p, stage, off, hipMemcpyHostToDevice, st));
+    for (auto& it : items) *it.dst = blob.p + it.off;
+    return AI_OK;
+  }
 };
 
 class Solver {
@@ -1138,22 +1186,27 @@ class Solver {
   TaskList fine, coarse;  // every active row
   TaskList lzf, lzc;      // rows of the Lanczos-mode segments only (grids of the step kernels)
   std::vector<TaskRange> h_cranges, h_segrange;
-  DevBuf<TaskRange> cranges, segrange;
+  Ptr<TaskRange> cranges, segrange;
+  DevBuf<char> blobA, blobB, blobC, resblob, lzres;
+  size_t rescap = 0;
   std::vector<int32_t> h_seg_start;
-  DevBuf<int32_t> seg_start, factive, cactive;
+  Ptr<int32_t> seg_start, factive, cactive;
   DevBuf<double> pvol, pA, pvolA, pvolB, psweep;
   DevBuf<double2> pB[2];
   DevBuf<MinMaxPart> pmm;
   // per-segment device arrays
-  DevBuf<int32_t> s_mode, s_needcc, s_frozen, s_m, s_ncomp, s_nosplit, s_kstar, s_split, s_ntrue, s_gstart, s_childA, s_childB, slots;
-  DevBuf<double> s_theta, s_resid, s_vol, s_volA, s_volB, s_scale, s_thr, s_costs, s_mcut, s_cu;
+  Ptr<int32_t> s_mode, s_needcc, s_gstart, s_childA, s_childB;  // uploaded per level (blobs)
+  Ptr<int32_t> s_split, s_ntrue, s_frozen, s_m;                  // downloaded per level (resblob / lzres)
+  Ptr<double> s_mcut, s_resid, s_theta;
+  DevBuf<int32_t> s_ncomp, s_nosplit, s_kstar, slots;
+  DevBuf<double> s_vol, s_volA, s_volB, s_scale, s_thr, s_costs, s_cu;
   // Lanczos history + vectors
   DevBuf<double> alpha_hist, b_hist, g_hist, coef, bnew_buf;
   int mcap = 0;
-  std::vector<double*> slabs;
+  std::vector<double*> slabs, owned_slabs;
   size_t slab_stride = 0;
   ~Solver() {
-    for (double* p : slabs) (void)hipFree(p);
+    for (double* p : owned_slabs) (void)hipFree(p);
     for (hipEvent_t e : evpool) (void)hipEventDestroy(e);
   }
 
@@ -1181,6 +1234,13 @@ class Solver {
     AI_TRY(Y.alloc(n));
     AI_TRY(b_parent[0].alloc(n));
     AI_TRY(b_parent[1].alloc(n));
+    // children never have more rows / entries than the chunk: size the ping-pong halves once
+    for (int h = 0; h < 2; ++h) {
+      AI_TRY(b_rowptr[h].alloc(n + 1));
+      AI_TRY(b_orig[h].alloc(n));
+      AI_TRY(b_col[h].alloc(e));
+      AI_TRY(b_wraw[h].alloc(e));
+    }
     AI_TRY(rcnt.alloc(n));
     AI_TRY(rc.alloc(n + 1));
     AI_TRY(ex.alloc(n + 1));
@@ -1200,28 +1260,29 @@ class Solver {
 
   int alloc_segs(int S_) {
     const size_t s = (size_t)S_ + 1;
-    AI_TRY(s_mode.ensure(s));
-    AI_TRY(s_needcc.ensure(s));
-    AI_TRY(s_frozen.ensure(s));
-    AI_TRY(s_m.ensure(s));
     AI_TRY(s_ncomp.ensure(s));
     AI_TRY(s_nosplit.ensure(s));
     AI_TRY(s_kstar.ensure(s));
-    AI_TRY(s_split.ensure(s));
-    AI_TRY(s_ntrue.ensure(s));
-    AI_TRY(s_gstart.ensure(s));
-    AI_TRY(s_childA.ensure(s));
-    AI_TRY(s_childB.ensure(s));
-    AI_TRY(s_theta.ensure(s));
-    AI_TRY(s_resid.ensure(s));
     AI_TRY(s_vol.ensure(s));
     AI_TRY(s_volA.ensure(s));
     AI_TRY(s_volB.ensure(s));
     AI_TRY(s_scale.ensure(s));
     AI_TRY(s_thr.ensure(s * AI_NUM_CUTS));
     AI_TRY(s_costs.ensure(s * AI_NUM_CUTS));
-    AI_TRY(s_mcut.ensure(s));
     AI_TRY(s_cu.ensure(s));
+    if (s > rescap) {
+      // results that the host reads every level sit together so that one copy fetches them
+      rescap = std::max(s, (size_t)128);
+      AI_TRY(resblob.alloc(rescap * 16));
+      AI_TRY(lzres.alloc(rescap * 24));
+    }
+    s_split.p = (int32_t*)resblob.p;
+    s_ntrue.p = s_split.p + rescap;
+    s_mcut.p = (double*)(s_ntrue.p + rescap);
+    s_m.p = (int32_t*)lzres.p;
+    s_frozen.p = s_m.p + rescap;
+    s_resid.p = (double*)(s_frozen.p + rescap);
+    s_theta.p = s_resid.p + rescap;
     return AI_OK;
   }
 
@@ -1285,24 +1346,20 @@ class Solver {
     }
     h_seg_start[S_] = S_ ? segs[S_ - 1].start + segs[S_ - 1].n : 0;
     AI_TRY(alloc_segs(S_));
-    AI_TRY(fine.d.ensure(fine.n + 1));
-    AI_TRY(fine.d_seg0.ensure(S_ + 1));
-    AI_TRY(coarse.d.ensure(coarse.n + 1));
-    AI_TRY(coarse.d_seg0.ensure(S_ + 1));
-    AI_TRY(seg_start.ensure(S_ + 1));
     AI_TRY(pvol.ensure(fine.n + 1));
     AI_TRY(psweep.ensure((size_t)(fine.n + 1) * AI_SWEEP_VALS));
     AI_TRY(pvolA.ensure(coarse.n + 1));
     AI_TRY(pvolB.ensure(coarse.n + 1));
     AI_TRY(pmm.ensure(coarse.n + 1));
-    AI_HIP(hipMemcpyAsync(fine.d.p, fine.h.data(), fine.n * sizeof(Task), hipMemcpyHostToDevice, st));
-    AI_HIP(hipMemcpyAsync(coarse.d.p, coarse.h.data(), coarse.n * sizeof(Task), hipMemcpyHostToDevice, st));
-    AI_HIP(hipMemcpyAsync(fine.d_seg0.p, fine.h_seg0.data(), (S_ + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    AI_HIP(hipMemcpyAsync(coarse.d_seg0.p, coarse.h_seg0.data(), (S_ + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    AI_HIP(hipMemcpyAsync(seg_start.p, h_seg_start.data(), (S_ + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    AI_HIP(hipMemcpyAsync(s_gstart.p, h_gstart.data(), (S_ + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    AI_HIP(hipMemcpyAsync(s_needcc.p, h_needcc.data(), (S_ + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    AI_HIP(hipStreamSynchronize(st));  // the host vectors must outlive the copies
+    Pack pk(ctx->stage, AI_STAGE_BYTES / 4);
+    pk.add(&fine.d.p, fine.h.data(), (size_t)fine.n);
+    pk.add(&coarse.d.p, coarse.h.data(), (size_t)coarse.n);
+    pk.add(&fine.d_seg0.p, fine.h_seg0.data(), (size_t)S_ + 1);
+    pk.add(&coarse.d_seg0.p, coarse.h_seg0.data(), (size_t)S_ + 1);
+    pk.add(&seg_start.p, h_seg_start.data(), (size_t)S_ + 1);
+    pk.add(&s_gstart.p, h_gstart.data(), (size_t)S_ + 1);
+    pk.add(&s_needcc.p, h_needcc.data(), (size_t)S_ + 1);
+    AI_TRY(pk.flush(blobA, st));
     return AI_OK;
   }
 
@@ -1330,10 +1387,12 @@ class Solver {
       AI_HIP(hipMemsetAsync(s_ncomp.p, 0, (size_t)S_ * sizeof(int32_t), st));
       hipLaunchKernelGGL(k_cc_count, dim3(coarse.n), dim3(AI_BLOCK), 0, st, coarse.d.p, parent, s_ncomp.p);
       AI_KERNEL_CHECK();
-      AI_HIP(hipMemcpyAsync(ncomp.data(), s_ncomp.p, (size_t)S_ * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      int32_t* dl = (int32_t*)(ctx->stage + AI_STAGE_BYTES / 2);
+      AI_HIP(hipMemcpyAsync(dl, s_ncomp.p, (size_t)S_ * sizeof(int32_t), hipMemcpyDeviceToHost, st));
       AI_HIP(hipStreamSynchronize(st));
+      for (int s = 0; s < S_; ++s) ncomp[s] = dl[s];
     }
-    std::vector<int32_t> mode(S_);
+    std::vector<int32_t> mode(S_ + 1, 0);
     for (int s = 0; s < S_; ++s) {
       segs[s].mode = (ncomp[s] > 1) ? 1 : 0;
       mode[s] = segs[s].mode;
@@ -1348,25 +1407,18 @@ class Solver {
     h_cranges.resize(lzc.n);
     for (int t = 0; t < lzc.n; ++t) h_cranges[t] = h_segrange[lzc.h[t].z];
     std::vector<int32_t> ones((size_t)std::max(lzf.n, lzc.n) + 1, 1);
-    AI_TRY(lzf.d.ensure(lzf.n + 1));
-    AI_TRY(lzc.d.ensure(lzc.n + 1));
-    AI_TRY(cranges.ensure(lzc.n + 1));
-    AI_TRY(segrange.ensure(S_ + 1));
-    AI_TRY(factive.ensure(lzf.n + 1));
-    AI_TRY(cactive.ensure(lzc.n + 1));
     AI_TRY(pA.ensure(lzf.n + 1));
     AI_TRY(pB[0].ensure(lzc.n + 1));
     AI_TRY(pB[1].ensure(lzc.n + 1));
-    AI_HIP(hipMemcpyAsync(s_mode.p, mode.data(), (size_t)S_ * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    AI_HIP(hipMemcpyAsync(segrange.p, h_segrange.data(), (size_t)(S_ + 1) * sizeof(TaskRange), hipMemcpyHostToDevice, st));
-    if (lzf.n) {
-      AI_HIP(hipMemcpyAsync(lzf.d.p, lzf.h.data(), (size_t)lzf.n * sizeof(Task), hipMemcpyHostToDevice, st));
-      AI_HIP(hipMemcpyAsync(lzc.d.p, lzc.h.data(), (size_t)lzc.n * sizeof(Task), hipMemcpyHostToDevice, st));
-      AI_HIP(hipMemcpyAsync(cranges.p, h_cranges.data(), (size_t)lzc.n * sizeof(TaskRange), hipMemcpyHostToDevice, st));
-      AI_HIP(hipMemcpyAsync(factive.p, ones.data(), (size_t)lzf.n * sizeof(int32_t), hipMemcpyHostToDevice, st));
-      AI_HIP(hipMemcpyAsync(cactive.p, ones.data(), (size_t)lzc.n * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    }
-    AI_HIP(hipStreamSynchronize(st));
+    Pack pk(ctx->stage + AI_STAGE_BYTES / 4, AI_STAGE_BYTES / 4);
+    pk.add(&s_mode.p, mode.data(), (size_t)S_ + 1);
+    pk.add(&segrange.p, h_segrange.data(), (size_t)S_ + 1);
+    pk.add(&lzf.d.p, lzf.h.data(), (size_t)lzf.n);
+    pk.add(&lzc.d.p, lzc.h.data(), (size_t)lzc.n);
+    pk.add(&cranges.p, h_cranges.data(), (size_t)lzc.n);
+    pk.add(&factive.p, ones.data(), (size_t)lzf.n);
+    pk.add(&cactive.p, ones.data(), (size_t)lzc.n);
+    AI_TRY(pk.flush(blobB, st));
     return AI_OK;
   }
 
@@ -1398,11 +1450,17 @@ class Solver {
   double* vec(int j) { return slabs[(size_t)j / AI_SLAB_VECS] + (size_t)(j % AI_SLAB_VECS) * slab_stride; }
   int ensure_vec(int j) {
     while ((size_t)j / AI_SLAB_VECS >= slabs.size()) {
+      const size_t bytes = (size_t)AI_SLAB_VECS * slab_stride * sizeof(double);
       double* p = nullptr;
-      hipError_t e = hipMalloc((void**)&p, (size_t)AI_SLAB_VECS * slab_stride * sizeof(double));
-      if (e != hipSuccess) {
-        ai_set_error("Lanczos vector slab %zu (%zu bytes) could not be allocated: %s", slabs.size(),
-                     (size_t)AI_SLAB_VECS * slab_stride * sizeof(double), hipGetErrorString(e));
+      if (ai_arena* a = ai_current_arena()) {
+        p = (double*)a->alloc(bytes);
+      } else if (hipMalloc((void**)&p, bytes) == hipSuccess) {
+        owned_slabs.push_back(p);
+      } else {
+        p = nullptr;
+      }
+      if (!p) {
+        ai_set_error("Lanczos vector slab %zu (%zu bytes) could not be allocated", slabs.size(), bytes);
         return AI_ERR_OOM;
       }
       slabs.push_back(p);
@@ -1451,9 +1509,7 @@ class Solver {
     // vectors live in slabs whose stride is the row count of the first level that needs them
     // (levels only shrink)
     if (slab_stride == 0) slab_stride = (size_t)na;
-    AI_HIP(hipMemsetAsync(s_frozen.p, 0, (size_t)S_ * sizeof(int32_t), st));
-    AI_HIP(hipMemsetAsync(s_m.p, 0, (size_t)S_ * sizeof(int32_t), st));
-    AI_HIP(hipMemsetAsync(s_resid.p, 0, (size_t)S_ * sizeof(double), st));
+    AI_HIP(hipMemsetAsync(lzres.p, 0, rescap * 24, st));  // m, frozen, resid, theta
     AI_HIP(hipMemsetAsync(slots.p, 0, AI_MAX_CHECKS * sizeof(int32_t), st));
     LzSeg L = lzseg();
     AI_TRY(ensure_vec(0));
@@ -1550,9 +1606,9 @@ class Solver {
     // ---- Ritz coefficients on the host (tiny), Ritz vectors on the device
     std::vector<int32_t> h_m(S_), h_frozen(S_);
     std::vector<double> h_a((size_t)S_ * mcap), h_b((size_t)S_ * (mcap + 1)), h_g((size_t)S_ * (mcap + 1)), h_coef((size_t)S_ * mcap, 0.0),
-        h_cu(S_, 0.0), h_resid(S_, 0.0);
-    AI_HIP(hipMemcpyAsync(h_m.data(), s_m.p, (size_t)S_ * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    AI_HIP(hipMemcpyAsync(h_frozen.data(), s_frozen.p, (size_t)S_ * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        h_cu(S_, 0.0), h_resid(S_, 0.0), h_theta(S_, 0.0);
+    char* dl = ctx->stage + AI_STAGE_BYTES / 2;
+    AI_HIP(hipMemcpyAsync(dl, lzres.p, rescap * 24, hipMemcpyDeviceToHost, st));
     {
       // only the columns the steps have filled
       const size_t wa = (size_t)std::min(steps, mcap) * sizeof(double), wb = (size_t)std::min(steps + 1, mcap + 1) * sizeof(double);
@@ -1560,8 +1616,13 @@ class Solver {
       AI_HIP(hipMemcpy2DAsync(h_b.data(), (size_t)(mcap + 1) * sizeof(double), b_hist.p, (size_t)(mcap + 1) * sizeof(double), wb, S_, hipMemcpyDeviceToHost, st));
       AI_HIP(hipMemcpy2DAsync(h_g.data(), (size_t)(mcap + 1) * sizeof(double), g_hist.p, (size_t)(mcap + 1) * sizeof(double), wb, S_, hipMemcpyDeviceToHost, st));
     }
-    AI_HIP(hipMemcpyAsync(h_resid.data(), s_resid.p, (size_t)S_ * sizeof(double), hipMemcpyDeviceToHost, st));
     AI_HIP(hipStreamSynchronize(st));
+    for (int s = 0; s < S_; ++s) {
+      h_m[s] = ((const int32_t*)dl)[s];
+      h_frozen[s] = ((const int32_t*)dl)[rescap + s];
+      h_resid[s] = ((const double*)(dl + rescap * 8))[s];
+      h_theta[s] = ((const double*)(dl + rescap * 16))[s];
+    }
     int max_m = 0;
     std::vector<double> sv;
     for (int s = 0; s < S_; ++s) {
@@ -1582,7 +1643,7 @@ class Solver {
       const double* b = &h_b[(size_t)s * (mcap + 1)];
       const double* g = &h_g[(size_t)s * (mcap + 1)];
       double theta = 0.0;
-      tridiag_top(a, b, m, &theta, sv);
+      tridiag_top(a, b, m, (h_frozen[s] && h_m[s] == m) ? &h_theta[s] : nullptr, &theta, sv);
       double cu = 0.0;
       for (int j = 0; j < m; ++j) {
         const double c = sv[j] / b[j];  // v_j = (R_j - g_j u1) / b_j
@@ -1635,10 +1696,19 @@ class Solver {
     h_split.resize(S_);
     h_ntrue.resize(S_);
     h_mcut.resize(S_);
-    AI_HIP(hipMemcpyAsync(h_split.data(), s_split.p, (size_t)S_ * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    AI_HIP(hipMemcpyAsync(h_ntrue.data(), s_ntrue.p, (size_t)S_ * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    AI_HIP(hipMemcpyAsync(h_mcut.data(), s_mcut.p, (size_t)S_ * sizeof(double), hipMemcpyDeviceToHost, st));
-    AI_HIP(hipStreamSynchronize(st));
+    {
+      char* dl = ctx->stage + AI_STAGE_BYTES / 2;
+      AI_HIP(hipMemcpyAsync(dl, resblob.p, rescap * 16, hipMemcpyDeviceToHost, st));
+      AI_HIP(hipStreamSynchronize(st));
+      const int32_t* sp = (const int32_t*)dl;
+      const int32_t* nt = sp + rescap;
+      const double* mc = (const double*)(nt + rescap);
+      for (int s = 0; s < S_; ++s) {
+        h_split[s] = sp[s];
+        h_ntrue[s] = nt[s];
+        h_mcut[s] = mc[s];
+      }
+    }
     float ms = 0.f;
     AI_HIP(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
     stats.ms_sweep += ms;
@@ -1670,6 +1740,7 @@ extern "C" int ai_ncut(ai_ctx* ctx, const ai_csr* csr, int64_t num_points_orig, 
   }
   AI_HIP(hipSetDevice(ctx->device));
   const double t0 = now_ms();
+  ArenaScope arena_scope(&ctx->arena);  // declared before the solver: its buffers die first
   Solver S(ctx, csr);
   fill_opts(S, opts);
   const int n = (int)csr->n;
@@ -1682,15 +1753,27 @@ extern "C" int ai_ncut(ai_ctx* ctx, const ai_csr* csr, int64_t num_points_orig, 
   hipStream_t st = ctx->stream;
   std::vector<int32_t> h_split, h_ntrue;
   std::vector<double> h_mcut;
+  bool pending_rebuild = false;
   while (S.S() > 0) {
     ++S.stats.levels;
     AI_TRY(S.build_tasks());
     AI_HIP(hipEventRecord(ctx->ev[4], st));
-    AI_TRY(S.prepare(true));
+    AI_TRY(S.prepare(true));  // synchronises: the previous level's rebuild events have completed
+    if (pending_rebuild) {
+      float ms2 = 0.f;
+      AI_HIP(hipEventElapsedTime(&ms2, ctx->ev[6], ctx->ev[7]));
+      S.stats.ms_rebuild += ms2;
+      pending_rebuild = false;
+    }
     AI_HIP(hipEventRecord(ctx->ev[5], st));
     AI_TRY(S.null_vectors());
     AI_TRY(S.lanczos(nullptr, nullptr, nullptr));
     AI_TRY(S.sweep(T, 0, h_split, h_ntrue, h_mcut));
+    {
+      float ms1 = 0.f;
+      AI_HIP(hipEventElapsedTime(&ms1, ctx->ev[4], ctx->ev[5]));
+      S.stats.ms_rebuild += ms1;
+    }
     // ---- children (deeper calls use split_lim = 0.01: normalized_cut.py:57-58 rely on the default)
     const int S_ = S.S();
     std::vector<SegHost> next;
@@ -1728,13 +1811,16 @@ extern "C" int ai_ncut(ai_ctx* ctx, const ai_csr* csr, int64_t num_points_orig, 
       }
     }
     AI_HIP(hipEventRecord(ctx->ev[6], st));
-    AI_HIP(hipMemcpyAsync(S.s_childA.p, cA.data(), (size_t)S_ * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    AI_HIP(hipMemcpyAsync(S.s_childB.p, cB.data(), (size_t)S_ * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    {
+      Pack pk(ctx->stage + 3 * (AI_STAGE_BYTES / 4), AI_STAGE_BYTES / 4);
+      pk.add(&S.s_childA.p, cA.data(), (size_t)S_);
+      pk.add(&S.s_childB.p, cB.data(), (size_t)S_);
+      AI_TRY(pk.flush(S.blobC, st));
+    }
     hipLaunchKernelGGL(k_split_flags, dim3(S.coarse.n), dim3(AI_BLOCK), 0, st, S.coarse.d.p, S.s_split.p, S.s_kstar.p, S.bin.p, S.flag.p);
     AI_KERNEL_CHECK();
     AI_TRY(ai_exclusive_scan_i32(st, S.flag.p, S.fscan.p, S.na, S.scantmp.p));
     const int pp = S.pp;
-    AI_TRY(S.b_orig[pp].ensure((size_t)std::max(cstart, 1)));
     hipLaunchKernelGGL(k_partition, dim3(S.coarse.n), dim3(AI_BLOCK), 0, st, S.coarse.d.p, S.seg_start.p, S.s_gstart.p, S.s_split.p, S.s_ntrue.p,
                        S.s_childA.p, S.s_childB.p, S.flag.p, S.fscan.p, S.orig, S.final_order.p, S.map.p, S.b_orig[pp].p);
     AI_KERNEL_CHECK();
@@ -1749,23 +1835,15 @@ extern "C" int ai_ncut(ai_ctx* ctx, const ai_csr* csr, int64_t num_points_orig, 
       AI_HIP(hipMemsetAsync(S.newcnt.p, 0, (size_t)(cstart + 1) * sizeof(int32_t), st));
       hipLaunchKernelGGL(k_rebuild_count, dim3(ge), dim3(AI_BLOCK), 0, st, S.rowptr, S.col, S.flag.p, S.map.p, S.na, S.newcnt.p);
       AI_KERNEL_CHECK();
-      AI_TRY(S.b_rowptr[pp].ensure((size_t)cstart + 1));
       AI_TRY(ai_exclusive_scan_i32(st, S.newcnt.p, S.b_rowptr[pp].p, cstart, S.scantmp.p));
-      int32_t new_nnz = 0;
-      AI_HIP(hipMemcpyAsync(&new_nnz, S.b_rowptr[pp].p + cstart, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-      AI_HIP(hipStreamSynchronize(st));
-      AI_TRY(S.b_col[pp].ensure((size_t)std::max(new_nnz, 1)));
-      AI_TRY(S.b_wraw[pp].ensure((size_t)std::max(new_nnz, 1)));
       hipLaunchKernelGGL(k_rebuild_fill, dim3(ge), dim3(AI_BLOCK), 0, st, S.rowptr, S.col, S.wraw, S.flag.p, S.map.p, S.na,
                          (const int32_t*)S.b_rowptr[pp].p, S.b_col[pp].p, S.b_wraw[pp].p);
       AI_KERNEL_CHECK();
     }
     AI_HIP(hipEventRecord(ctx->ev[7], st));
-    AI_HIP(hipStreamSynchronize(st));  // cA / cB are read by the copies above
-    float ms1 = 0.f, ms2 = 0.f;
-    AI_HIP(hipEventElapsedTime(&ms1, ctx->ev[4], ctx->ev[5]));
-    AI_HIP(hipEventElapsedTime(&ms2, ctx->ev[6], ctx->ev[7]));
-    S.stats.ms_rebuild += ms1 + ms2;
+    // no sync here: the next level's first host read (component counts) waits for all of this,
+    // and the partition / rebuild time is collected there
+    pending_rebuild = true;
     S.rowptr = S.b_rowptr[pp].p;
     S.col = S.b_col[pp].p;
     S.wraw = S.b_wraw[pp].p;
@@ -1779,6 +1857,11 @@ extern "C" int ai_ncut(ai_ctx* ctx, const ai_csr* csr, int64_t num_points_orig, 
   std::vector<int32_t> order((size_t)n);
   AI_HIP(hipMemcpyAsync(order.data(), S.final_order.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   AI_HIP(hipStreamSynchronize(st));
+  if (pending_rebuild) {
+    float ms2 = 0.f;
+    AI_HIP(hipEventElapsedTime(&ms2, ctx->ev[6], ctx->ev[7]));
+    S.stats.ms_rebuild += ms2;
+  }
   std::sort(leaf_starts.begin(), leaf_starts.end());
   int g = -1;
   size_t li = 0;
@@ -1814,6 +1897,7 @@ extern "C" int ai_fiedler(ai_ctx* ctx, const ai_csr* csr, const ai_ncut_opts* op
     return AI_ERR_BAD_ARG;
   }
   AI_HIP(hipSetDevice(ctx->device));
+  ArenaScope arena_scope(&ctx->arena);  // declared before the solver: its buffers die first
   Solver S(ctx, csr);
   fill_opts(S, opts);
   const int n = (int)csr->n;
@@ -1850,6 +1934,7 @@ extern "C" int ai_sweep(ai_ctx* ctx, const ai_csr* csr, const double* ev, double
     return AI_ERR_BAD_ARG;
   }
   AI_HIP(hipSetDevice(ctx->device));
+  ArenaScope arena_scope(&ctx->arena);  // declared before the solver: its buffers die first
   Solver S(ctx, csr);
   const int n = (int)csr->n;
   AI_TRY(S.begin(true));
@@ -1890,6 +1975,7 @@ extern "C" int ai_lsym_apply(ai_ctx* ctx, const ai_csr* csr, const double* x, do
     return AI_ERR_BAD_ARG;
   }
   AI_HIP(hipSetDevice(ctx->device));
+  ArenaScope arena_scope(&ctx->arena);  // declared before the solver: its buffers die first
   Solver S(ctx, csr);
   const int n = (int)csr->n;
   AI_TRY(S.begin(true));
@@ -1920,6 +2006,7 @@ extern "C" int ai_bench_spmv(ai_ctx* ctx, const ai_csr* csr, int32_t reps, doubl
     return AI_ERR_BAD_ARG;
   }
   AI_HIP(hipSetDevice(ctx->device));
+  ArenaScope arena_scope(&ctx->arena);  // declared before the solver: its buffers die first
   Solver S(ctx, csr);
   AI_TRY(S.begin(true));
   AI_TRY(S.build_tasks());
