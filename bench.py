@@ -4,12 +4,14 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path over one chunk: affinity build (TARL + spatial) from
+One "step" = one pass of the hot path over one batch of chunks per GPU (`--in-flight`, default 4
+independent chunks, each on its own context / HIP streams): affinity build (TARL + spatial) from
 inputs already resident in HBM, recursive normalized cut, labels back on the host, and (N > 1)
-the gather of the label arrays to rank 0.  Workload = BASELINE.json configs[1]: a 200 000-point
+the gather of the label arrays to rank 0.  Several chunks are kept in flight because one chunk's
+kernels are latency-bound (small frontiers); the single-chunk latency is reported next to it.  Workload = BASELINE.json configs[1]: a 200 000-point
 chunk, alpha = 1, theta = 0.5 (96-d features), T = 0.03; synthetic surface chunk.
 Chunks are independent, so ranks process different chunks with no data-path collective
-("weak" scaling: one chunk per rank per step).
+("weak" scaling: the same number of chunks per rank per step).
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the fused Lanczos SpMV,
 `k_lz_spmv`): algorithmic bytes of its launches / their summed duration, both from a profiled
@@ -70,6 +72,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--in-flight", type=int, default=4, help="independent chunks processed concurrently per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -91,23 +94,36 @@ def main():
     from autoinst_amd import ncuts_api as api
     from autoinst_amd import sharding, synth
 
-    ctx = api.Context(local_rank)
-    # one chunk per rank (different seeds = different chunks of the map), resident in HBM
-    ch = synth.synthetic_chunk(N_POINTS, seed=rank, tarl=True)
-    dev = torch.device("cuda", local_rank)
-    pts_d = torch.from_numpy(ch["points"]).to(dev)
-    tarl_d = torch.from_numpy(ch["tarl"]).to(dev)
-    torch.cuda.synchronize()
+    from concurrent.futures import ThreadPoolExecutor
 
-    def step(profile=False):
-        g = api.build_affinity(pts_d, tarl_d, alpha=CFG["alpha"], theta=CFG["theta"], gamma=CFG["gamma"], ctx=ctx)
+    K = max(1, args.in_flight)
+    dev = torch.device("cuda", local_rank)
+    # K chunks per rank per step, each on its own context (own HIP streams + workspace), all
+    # resident in HBM.  Different seeds = different chunks of the map.
+    ctxs = [api.Context(local_rank) for _ in range(K)]
+    data = []
+    for k in range(K):
+        ch = synth.synthetic_chunk(N_POINTS, seed=rank * K + k, tarl=True)
+        data.append((torch.from_numpy(ch["points"]).to(dev), torch.from_numpy(ch["tarl"]).to(dev)))
+    torch.cuda.synchronize()
+    pool = ThreadPoolExecutor(max_workers=K)
+
+    def one_chunk(k, profile=False):
+        pts_d, tarl_d = data[k]
+        g = api.build_affinity(pts_d, tarl_d, alpha=CFG["alpha"], theta=CFG["theta"], gamma=CFG["gamma"], ctx=ctxs[k])
         try:
             lab, ng, st = api.ncuts_labels(g, N_POINTS, CFG["T"], time_spmv=profile)
         finally:
             nnz = g.nnz
             g.free()
-        merged = sharding.gather_labels({rank: lab}, device=dev) if world > 1 else {rank: lab}
-        return lab, ng, st, nnz, merged
+        return lab, ng, st, nnz
+
+    def step():
+        # the library calls release the GIL, so the K chunks really are in flight together
+        res = list(pool.map(one_chunk, range(K)))
+        local = {rank * K + k: res[k][0] for k in range(K)}
+        merged = sharding.gather_labels(local, device=dev) if world > 1 else local
+        return res, merged
 
     def barrier():
         if world > 1:
@@ -127,20 +143,25 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    lab, ng, st, nnz, merged = last
+    res, merged = last
+    lab, ng, st, nnz = res[0]
 
-    # profiled repeat of the same step: HIP events around every SpMV launch (rank 0 reports)
-    _, _, stp, _, _ = step(profile=True)
+    # one chunk alone (latency), then a profiled repeat: HIP start/stop events on every SpMV dispatch
+    t1 = time.perf_counter()
+    for _ in range(3):
+        one_chunk(0)
+    latency_ms = 1e3 * (time.perf_counter() - t1) / 3
+    _, _, stp, _ = one_chunk(0, profile=True)
     barrier()
 
     if rank == 0:
-        assert merged is not None and len(merged) == world and all(v.shape[0] == N_POINTS for v in merged.values())
+        assert merged is not None and len(merged) == world * K and all(v.shape[0] == N_POINTS for v in merged.values())
         launches = int(stp["lanczos_steps"])
         b = spmv_bytes(int(stp["spmv_rows"]), int(stp["spmv_nnz"]), launches)
         ach = b / (stp["ms_spmv"] * 1e-3) / 1e9 if stp["ms_spmv"] > 0 else 0.0
         out = {
             "metric": "chunks/sec (200k-pt TARL+Spatial NCuts chunk: affinity build + recursive normalized cut)",
-            "value": world * args.steps / elapsed,
+            "value": world * K * args.steps / elapsed,
             "unit": "chunks/sec",
             "n_gpus": world,
             "steps": args.steps,
@@ -152,8 +173,10 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "configs[1]: single 200k-point surface chunk, TARL(96-d)+Spatial affinities, "
-                                   "alpha=1 theta=0.5 T=0.03, one chunk per GPU per step",
-                       "n_points": N_POINTS, "nnz": int(nnz), "chunks_per_step": world, "parallelism": f"chunk-dp{world}"},
+                                   f"alpha=1 theta=0.5 T=0.03; {K} independent chunks in flight per GPU per step",
+                       "n_points": N_POINTS, "nnz": int(nnz), "chunks_per_step": world * K, "chunks_in_flight_per_gpu": K,
+                       "parallelism": f"chunk-dp{world}"},
+            "single_chunk_latency_ms": latency_ms,
             "eigensolve_ms": st["ms_eigen"],
             "ncut_ms": st["ms_total"],
             "sweep_ms": st["ms_sweep"],
