@@ -19,7 +19,8 @@ NUM_CUTS = 10
 SYMBOLS = (
     "ai_version", "ai_last_error", "ai_ctx_create", "ai_ctx_destroy", "ai_affinity_build",
     "ai_csr_from_host", "ai_csr_dims", "ai_csr_export", "ai_csr_free", "ai_ncut", "ai_fiedler",
-    "ai_sweep", "ai_lsym_apply", "ai_bench_spmv",
+    "ai_sweep", "ai_lsym_apply", "ai_bench_spmv", "ai_eigs_smallest",
+    "ai_radius_mean_pool", "ai_nn1_project",
 )
 
 
@@ -76,6 +77,9 @@ def load():
     lib.ai_sweep.argtypes = [vp, vp, vp, vp, vp, P(dbl)]
     lib.ai_lsym_apply.argtypes = [vp, vp, vp, vp]
     lib.ai_bench_spmv.argtypes = [vp, vp, i32, P(dbl), P(dbl)]
+    lib.ai_eigs_smallest.argtypes = [vp, vp, i32, P(NcutOpts), vp, vp, P(i32), P(dbl)]
+    lib.ai_radius_mean_pool.argtypes = [vp, vp, i64, vp, i64, vp, i32, dbl, C.c_int, vp, vp]
+    lib.ai_nn1_project.argtypes = [vp, vp, i64, vp, i64, C.c_int, vp, vp]
     for name in SYMBOLS:
         if name not in ("ai_version", "ai_last_error"):
             getattr(lib, name).restype = C.c_int

@@ -645,6 +645,145 @@ __global__ __launch_bounds__(AI_BLOCK) void k_ritz(const Task* __restrict__ ctas
   }
 }
 
+// ----------------------------------------------------------------------------- full re-orthogonalisation (ai_eigs_smallest)
+// For k > 2 eigenpairs the three-term recurrence alone is not enough: once a Ritz pair has
+// converged, copies of it re-enter.  Each new vector r = R_{j+1} is therefore orthogonalised
+// against ALL kept Lanczos vectors v_i = (R_i - g_i u1) / b_i, i <= j, before it is normalised:
+//   c_i = v_i . r = (R_i . r - g_i (u1 . r)) / b_i,   r <- r - sum_i c_i v_i.
+#define FRO_CH 16
+
+// part[task][i] = sum over the task's rows of R_i[row] * r[row], 16 vectors per block
+__global__ __launch_bounds__(AI_BLOCK) void k_fro_dots(const Task* __restrict__ ctasks, const double* __restrict__ r,
+                                                       double* const* __restrict__ slabs, size_t stride, int nvec,
+                                                       double* __restrict__ part, int pitch) {
+  constexpr int RPT = AI_COARSE_ROWS / AI_BLOCK;
+  __shared__ double sm[FRO_CH][AI_BLOCK / 64];
+  const Task tk = ctasks[blockIdx.x];
+  const int i0 = blockIdx.y * FRO_CH;
+  double rv[RPT];
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    const int row = tk.x + threadIdx.x + q * AI_BLOCK;
+    rv[q] = (row < tk.y) ? r[row] : 0.0;
+  }
+  double acc[FRO_CH];
+#pragma unroll
+  for (int ii = 0; ii < FRO_CH; ++ii) {
+    acc[ii] = 0.0;
+    const int i = i0 + ii;
+    if (i < nvec) {
+      const double* Ri = slabs[i / AI_SLAB_VECS] + (size_t)(i % AI_SLAB_VECS) * stride;
+#pragma unroll
+      for (int q = 0; q < RPT; ++q) {
+        const int row = tk.x + threadIdx.x + q * AI_BLOCK;
+        if (row < tk.y) acc[ii] = fma(rv[q], Ri[row], acc[ii]);
+      }
+    }
+  }
+  const int w = threadIdx.x >> 6, ln = threadIdx.x & 63;
+#pragma unroll
+  for (int ii = 0; ii < FRO_CH; ++ii) {
+    const double v = ai_wave_sum(acc[ii]);
+    if (ln == 0) sm[ii][w] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < FRO_CH && i0 + (int)threadIdx.x < nvec) {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < AI_BLOCK / 64; ++i) t += sm[threadIdx.x][i];
+    part[(size_t)blockIdx.x * pitch + i0 + threadIdx.x] = t;
+  }
+}
+
+// coef_i = c_i / b_i and cu = sum_i c_i g_i / b_i (one block; fixed summation orders)
+__global__ __launch_bounds__(AI_BLOCK) void k_fro_coef(int ntask, const double* __restrict__ part, int pitch, int nvec,
+                                                       const double* __restrict__ g_hist, const double* __restrict__ b_hist,
+                                                       const double2* __restrict__ pBr, double* __restrict__ coef,
+                                                       double* __restrict__ cu) {
+  __shared__ double sm[AI_BLOCK / 64];
+  double gq = 0.0;
+  for (int t = threadIdx.x; t < ntask; t += AI_BLOCK) gq += pBr[t].y;
+  gq = ai_block_sum(gq, sm);  // u1 . r
+  double cuacc = 0.0;
+  for (int i = threadIdx.x; i < nvec; i += AI_BLOCK) {
+    double d = 0.0;
+    for (int t = 0; t < ntask; ++t) d += part[(size_t)t * pitch + i];
+    const double rb = 1.0 / b_hist[i];
+    const double c = (d - g_hist[i] * gq) * rb;
+    coef[i] = c * rb;
+    cuacc += c * g_hist[i] * rb;
+  }
+  const double tot = ai_block_sum(cuacc, sm);
+  if (threadIdx.x == 0) cu[0] = tot;
+}
+
+// r <- r - sum_i coef_i R_i + cu u1; new partials (r.r, u1.r)
+__global__ __launch_bounds__(AI_BLOCK) void k_fro_apply(const Task* __restrict__ ctasks, double* __restrict__ r,
+                                                        double* const* __restrict__ slabs, size_t stride, int nvec,
+                                                        const double* __restrict__ coef, const double* __restrict__ cu,
+                                                        const double* __restrict__ u1, double2* __restrict__ pBout) {
+  constexpr int RPT = AI_COARSE_ROWS / AI_BLOCK;
+  __shared__ double sm[AI_BLOCK / 64];
+  const Task tk = ctasks[blockIdx.x];
+  double rv[RPT];
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    const int row = tk.x + threadIdx.x + q * AI_BLOCK;
+    rv[q] = (row < tk.y) ? r[row] : 0.0;
+  }
+  for (int i = 0; i < nvec; ++i) {
+    const double* Ri = slabs[i / AI_SLAB_VECS] + (size_t)(i % AI_SLAB_VECS) * stride;
+    const double c = coef[i];
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      const int row = tk.x + threadIdx.x + q * AI_BLOCK;
+      if (row < tk.y) rv[q] = fma(-c, Ri[row], rv[q]);
+    }
+  }
+  const double cuv = cu[0];
+  double nn = 0.0, gg = 0.0;
+#pragma unroll
+  for (int q = 0; q < RPT; ++q) {
+    const int row = tk.x + threadIdx.x + q * AI_BLOCK;
+    if (row < tk.y) {
+      const double ui = u1[row];
+      const double v = fma(cuv, ui, rv[q]);
+      r[row] = v;
+      nn = fma(v, v, nn);
+      gg = fma(ui, v, gg);
+    }
+  }
+  const double tn = ai_block_sum(nn, sm);
+  const double tg = ai_block_sum(gg, sm);
+  if (threadIdx.x == 0) pBout[blockIdx.x] = make_double2(tn, tg);
+}
+
+// out[i][row] (+)= sum_j coefT[j][i] R_j[row] for up to 64 Ritz vectors at once, one slab per launch;
+// the first launch starts from cu_i u1[row]
+#define RITZ_MAXK 64
+__global__ __launch_bounds__(AI_BLOCK) void k_ritz_multi(const Task* __restrict__ ctasks, int kv, const double* __restrict__ coefT,
+                                                         const double* __restrict__ cuv, const double* __restrict__ u1,
+                                                         const double* __restrict__ slab, size_t stride, int j0, int nvec, int m,
+                                                         int first, double* __restrict__ out, size_t out_stride) {
+  const Task tk = ctasks[blockIdx.x];
+  const int jn = min(nvec, m - j0);
+  for (int row = tk.x + threadIdx.x; row < tk.y; row += AI_BLOCK) {
+    double acc[RITZ_MAXK];
+    const double ui = u1[row];
+#pragma unroll
+    for (int i = 0; i < RITZ_MAXK; ++i) acc[i] = (i < kv) ? (first ? cuv[i] * ui : out[(size_t)i * out_stride + row]) : 0.0;
+    for (int j = 0; j < jn; ++j) {
+      const double v = slab[(size_t)j * stride + row];
+      const double* cj = coefT + (size_t)(j0 + j) * RITZ_MAXK;
+#pragma unroll
+      for (int i = 0; i < RITZ_MAXK; ++i) acc[i] = fma(cj[i], v, acc[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < RITZ_MAXK; ++i)
+      if (i < kv) out[(size_t)i * out_stride + row] = acc[i];
+  }
+}
+
 // ----------------------------------------------------------------------------- threshold sweep
 struct MinMaxPart {
   double mn, mx, sumsq, amax;
@@ -1089,6 +1228,89 @@ static void tridiag_top(const double* a, const double* b, int m, const double* h
     for (int i = 0; i < m; ++i) x[i] *= rn;
   }
   s = x;
+}
+
+// idx-th largest eigenvalue (idx = 0: the largest) of T by bisection on Sturm counts
+static double tridiag_eigval(const double* a, const double* b, int m, int idx, double lo, double hi) {
+  const int need = m - idx;  // smallest x with count_lt(x) >= need is just above the wanted eigenvalue
+  for (int it = 0; it < 200; ++it) {
+    const double mid = 0.5 * (lo + hi);
+    if (mid <= lo || mid >= hi) break;
+    if (sturm_lt_host(a, b, m, mid) >= need) hi = mid; else lo = mid;
+  }
+  return 0.5 * (lo + hi);
+}
+
+// eigenvector of T for the (already located) eigenvalue theta: pivoted LU + inverse iteration,
+// kept orthogonal to `prev` (eigenvectors of neighbouring eigenvalues, as LAPACK dstein does)
+static void tridiag_eigvec(const double* a, const double* b, int m, double theta, const std::vector<std::vector<double>>& prev,
+                           const std::vector<int>& cluster, std::vector<double>& x) {
+  x.assign(m, 0.0);
+  if (m == 1) {
+    x[0] = 1.0;
+    return;
+  }
+  double nrm = 0.0;
+  for (int i = 0; i < m; ++i) nrm = std::max(nrm, fabs(a[i]) + (i > 0 ? fabs(b[i]) : 0.0) + (i + 1 < m ? fabs(b[i + 1]) : 0.0));
+  std::vector<double> d(m), du(m, 0.0), du2(m, 0.0), dl(m, 0.0);
+  std::vector<int> piv(m, 0);
+  const double tiny = 2.3e-16 * std::max(nrm, 1e-300);
+  for (int i = 0; i < m; ++i) d[i] = a[i] - theta;
+  for (int i = 0; i + 1 < m; ++i) {
+    du[i] = b[i + 1];
+    dl[i] = b[i + 1];
+  }
+  for (int i = 0; i + 1 < m; ++i) {
+    if (fabs(d[i]) >= fabs(dl[i])) {
+      if (fabs(d[i]) < tiny) d[i] = tiny;
+      const double f = dl[i] / d[i];
+      dl[i] = f;
+      d[i + 1] -= f * du[i];
+      du2[i] = 0.0;
+      piv[i] = 0;
+    } else {
+      const double f = d[i] / dl[i];
+      d[i] = dl[i];
+      dl[i] = f;
+      const double t = du[i];
+      du[i] = d[i + 1];
+      d[i + 1] = t - f * du[i];
+      if (i + 2 < m) {
+        du2[i] = du[i + 1];
+        du[i + 1] = -f * du[i + 1];
+      }
+      piv[i] = 1;
+    }
+  }
+  if (fabs(d[m - 1]) < tiny) d[m - 1] = tiny;
+  for (int i = 0; i < m; ++i) x[i] = 1.0 + 0.001 * ((i * 2654435761u) % 1000) / 1000.0;
+  for (int iter = 0; iter < 5; ++iter) {
+    for (int c : cluster) {  // stay orthogonal to the eigenvectors of the cluster found so far
+      double dot = 0.0;
+      for (int i = 0; i < m; ++i) dot += prev[c][i] * x[i];
+      for (int i = 0; i < m; ++i) x[i] -= dot * prev[c][i];
+    }
+    for (int i = 0; i + 1 < m; ++i) {
+      if (piv[i]) std::swap(x[i], x[i + 1]);
+      x[i + 1] -= dl[i] * x[i];
+    }
+    x[m - 1] /= d[m - 1];
+    if (m >= 2) x[m - 2] = (x[m - 2] - du[m - 2] * x[m - 1]) / d[m - 2];
+    for (int i = m - 3; i >= 0; --i) x[i] = (x[i] - du[i] * x[i + 1] - du2[i] * x[i + 2]) / d[i];
+    double n2 = 0.0;
+    for (int i = 0; i < m; ++i) n2 += x[i] * x[i];
+    const double rn = 1.0 / sqrt(n2);
+    for (int i = 0; i < m; ++i) x[i] *= rn;
+  }
+  for (int c : cluster) {
+    double dot = 0.0;
+    for (int i = 0; i < m; ++i) dot += prev[c][i] * x[i];
+    for (int i = 0; i < m; ++i) x[i] -= dot * prev[c][i];
+  }
+  double n2 = 0.0;
+  for (int i = 0; i < m; ++i) n2 += x[i] * x[i];
+  const double rn = 1.0 / sqrt(n2);
+  for (int i = 0; i < m; ++i) x[i] *= rn;
 }
 
 // ----------------------------------------------------------------------------- host: driver
@@ -1677,6 +1899,173 @@ class Solver {
     return AI_OK;
   }
 
+  // ---- k1 largest eigenpairs of the deflated M (= the k1 smallest non-zero of L) of ONE connected
+  // segment: Lanczos with full re-orthogonalisation.  thetas[i] descending; Ritz vectors into
+  // out (k1 x out_stride, compact row order).
+  DevBuf<double*> d_slabtab;
+  DevBuf<double> fro_part, fro_coef, fro_cu, coefT, cuv;
+  size_t slabtab_n = 0;
+  int sync_slabtab() {
+    if (slabtab_n == slabs.size()) return AI_OK;
+    AI_TRY(d_slabtab.ensure(512));
+    AI_HIP(hipMemcpyAsync(d_slabtab.p, slabs.data(), slabs.size() * sizeof(double*), hipMemcpyHostToDevice, st));
+    AI_HIP(hipStreamSynchronize(st));
+    slabtab_n = slabs.size();
+    return AI_OK;
+  }
+
+  int lanczos_fro(int k1, std::vector<double>& thetas, std::vector<double>& resids, double* out, size_t out_stride, int* steps_out) {
+    const int S_ = S();
+    if (S_ != 1 || segs[0].mode != 0) {
+      ai_set_error("internal: lanczos_fro needs one connected segment");
+      return AI_ERR_INTERNAL;
+    }
+    const int n = segs[0].n;
+    mcap = std::max(1, std::min(opt.max_iter, n - 1));
+    if (k1 > mcap) k1 = mcap;
+    {
+      const size_t scap = 128, mc = (size_t)std::max(mcap, opt.max_iter);
+      AI_TRY(alpha_hist.ensure(scap * mc));
+      AI_TRY(b_hist.ensure(scap * (mc + 1)));
+      AI_TRY(g_hist.ensure(scap * (mc + 1)));
+      AI_TRY(bnew_buf.ensure((size_t)AI_CHECK_DEPTH * (scap + 1)));
+    }
+    const int pitch = mcap + 1;
+    AI_TRY(fro_part.ensure((size_t)lzc.n * pitch));
+    AI_TRY(fro_coef.ensure((size_t)pitch));
+    AI_TRY(fro_cu.ensure(8));
+    if (slab_stride == 0) slab_stride = (size_t)na;
+    AI_HIP(hipMemsetAsync(lzres.p, 0, rescap * 24, st));
+    LzSeg L = lzseg();
+    AI_TRY(ensure_vec(0));
+    AI_TRY(ensure_vec(1));
+    hipLaunchKernelGGL(k_lz_init, dim3(lzc.n), dim3(AI_BLOCK), 0, st, lzc.d.p, cactive.p, orig, u1.p, vec(0), pB[0].p);
+    AI_KERNEL_CHECK();
+    std::vector<double> h_a, h_b, h_g;
+    std::vector<std::vector<double>> svec;
+    int m = 0;
+    bool done = false;
+    const int chk = std::max(8, opt.check_every);
+    int next_check = std::max(2 * k1, chk);
+    for (int j = 0; j < mcap && !done; ++j) {
+      AI_TRY(ensure_vec(j + 1));
+      AI_TRY(sync_slabtab());
+      AI_TRY(launch_spmv(j));
+      hipLaunchKernelGGL(k_lz_update, dim3(lzc.n), dim3(AI_BLOCK), 0, st, lzc.d.p, cranges.p, L, j, (const double*)pA.p,
+                         (const double2*)pB[j & 1].p, pB[(j + 1) & 1].p, u1.p, (const double*)Y.p, (const double*)vec(j),
+                         (const double*)vec(j > 0 ? j - 1 : 0), vec(j + 1));
+      AI_KERNEL_CHECK();
+      // full re-orthogonalisation of R_{j+1} against v_0 .. v_j (two passes: "twice is enough")
+      for (int pass = 0; pass < 2; ++pass) {
+        const int nvec = j + 1;
+        hipLaunchKernelGGL(k_fro_dots, dim3(lzc.n, (nvec + FRO_CH - 1) / FRO_CH), dim3(AI_BLOCK), 0, st, lzc.d.p, (const double*)vec(j + 1),
+                           (double* const*)d_slabtab.p, slab_stride, nvec, fro_part.p, pitch);
+        AI_KERNEL_CHECK();
+        hipLaunchKernelGGL(k_fro_coef, dim3(1), dim3(AI_BLOCK), 0, st, lzc.n, (const double*)fro_part.p, pitch, nvec, (const double*)g_hist.p,
+                           (const double*)b_hist.p, (const double2*)pB[(j + 1) & 1].p, fro_coef.p, fro_cu.p);
+        AI_KERNEL_CHECK();
+        hipLaunchKernelGGL(k_fro_apply, dim3(lzc.n), dim3(AI_BLOCK), 0, st, lzc.d.p, vec(j + 1), (double* const*)d_slabtab.p, slab_stride, nvec,
+                           (const double*)fro_coef.p, (const double*)fro_cu.p, u1.p, pB[(j + 1) & 1].p);
+        AI_KERNEL_CHECK();
+      }
+      m = j + 1;
+      if (m >= next_check || m == mcap) {
+        next_check = m + chk;
+        // T_m and b_m to the host; the innermost wanted pair converges last: look at it first
+        double* bn = bnew_buf.p;
+        hipLaunchKernelGGL(k_lz_bnew, dim3(1), dim3(64), 0, st, segrange.p, s_mode.p, s_frozen.p, (const double2*)pB[(j + 1) & 1].p, bn);
+        AI_KERNEL_CHECK();
+        h_a.resize(m);
+        h_b.resize(m + 1);
+        AI_HIP(hipMemcpyAsync(h_a.data(), alpha_hist.p, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, st));
+        AI_HIP(hipMemcpyAsync(h_b.data(), b_hist.p, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, st));
+        AI_HIP(hipMemcpyAsync(&h_b[m], bn, sizeof(double), hipMemcpyDeviceToHost, st));
+        int32_t frozen = 0;
+        AI_HIP(hipMemcpyAsync(&frozen, s_frozen.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        AI_HIP(hipStreamSynchronize(st));
+        const int kk = std::min(k1, m);
+        double glo = -1e300, ghi = -1e300;
+        for (int i = 0; i < m; ++i) {
+          glo = std::max(glo, h_a[i]);
+          ghi = std::max(ghi, h_a[i] + (i > 0 ? fabs(h_b[i]) : 0.0) + (i + 1 < m ? fabs(h_b[i + 1]) : 0.0));
+        }
+        double gmin = 1e300;
+        for (int i = 0; i < m; ++i) gmin = std::min(gmin, h_a[i] - (i > 0 ? fabs(h_b[i]) : 0.0) - (i + 1 < m ? fabs(h_b[i + 1]) : 0.0));
+        ghi += 1e-14 * std::max(fabs(ghi), 1.0);
+        gmin -= 1e-14 * std::max(fabs(gmin), 1.0);
+        std::vector<double> sv;
+        std::vector<std::vector<double>> none;
+        std::vector<int> nocl;
+        const double th_in = tridiag_eigval(h_a.data(), h_b.data(), m, kk - 1, gmin, ghi);
+        tridiag_eigvec(h_a.data(), h_b.data(), m, th_in, none, nocl, sv);
+        const double r_in = fabs(h_b[m] * sv[m - 1]);
+        if (getenv("AI_NCUT_DEBUG")) fprintf(stderr, "[ai_eigs] m=%d innermost theta=%.12f resid=%.3e\n", m, th_in, r_in);
+        if ((r_in <= opt.tol && kk == k1) || m == mcap || frozen) done = true;
+        if (frozen) {
+          // Krylov space exhausted inside the update kernel: T stops at the size recorded there
+          int32_t fm = m;
+          AI_HIP(hipMemcpyAsync(&fm, s_m.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+          AI_HIP(hipStreamSynchronize(st));
+          m = std::max(1, std::min(m, (int)fm));
+        }
+      }
+    }
+    if (steps_out) *steps_out = m;
+    // ---- all k1 Ritz pairs of T_m on the host
+    h_a.resize(m);
+    h_b.resize(m + 1);
+    h_g.resize(m);
+    AI_HIP(hipMemcpyAsync(h_a.data(), alpha_hist.p, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, st));
+    AI_HIP(hipMemcpyAsync(h_b.data(), b_hist.p, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, st));
+    AI_HIP(hipMemcpyAsync(h_g.data(), g_hist.p, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, st));
+    {
+      hipLaunchKernelGGL(k_lz_bnew, dim3(1), dim3(64), 0, st, segrange.p, s_mode.p, s_frozen.p, (const double2*)pB[m & 1].p, bnew_buf.p);
+      AI_KERNEL_CHECK();
+      AI_HIP(hipMemcpyAsync(&h_b[m], bnew_buf.p, sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    AI_HIP(hipStreamSynchronize(st));
+    const int kk = std::min(k1, m);
+    double ghi = -1e300, gmin = 1e300, nrm = 0.0;
+    for (int i = 0; i < m; ++i) {
+      const double rad = (i > 0 ? fabs(h_b[i]) : 0.0) + (i + 1 < m ? fabs(h_b[i + 1]) : 0.0);
+      ghi = std::max(ghi, h_a[i] + rad);
+      gmin = std::min(gmin, h_a[i] - rad);
+      nrm = std::max(nrm, fabs(h_a[i]) + rad);
+    }
+    ghi += 1e-14 * std::max(fabs(ghi), 1.0);
+    gmin -= 1e-14 * std::max(fabs(gmin), 1.0);
+    thetas.assign(kk, 0.0);
+    resids.assign(kk, 0.0);
+    svec.assign(kk, std::vector<double>());
+    std::vector<double> h_coefT((size_t)m * RITZ_MAXK, 0.0), h_cuv(RITZ_MAXK, 0.0);
+    for (int i = 0; i < kk; ++i) {
+      thetas[i] = tridiag_eigval(h_a.data(), h_b.data(), m, i, gmin, ghi);
+      std::vector<int> cluster;
+      for (int c = 0; c < i; ++c)
+        if (fabs(thetas[c] - thetas[i]) <= 1e-3 * nrm) cluster.push_back(c);
+      tridiag_eigvec(h_a.data(), h_b.data(), m, thetas[i], svec, cluster, svec[i]);
+      resids[i] = fabs(h_b[m] * svec[i][m - 1]);
+      double cu = 0.0;
+      for (int j = 0; j < m; ++j) {
+        const double c = svec[i][j] / h_b[j];
+        h_coefT[(size_t)j * RITZ_MAXK + i] = c;
+        cu -= c * h_g[j];
+      }
+      h_cuv[i] = cu;
+    }
+    AI_TRY(coefT.ensure(h_coefT.size()));
+    AI_TRY(cuv.ensure(RITZ_MAXK));
+    AI_HIP(hipMemcpyAsync(coefT.p, h_coefT.data(), h_coefT.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    AI_HIP(hipMemcpyAsync(cuv.p, h_cuv.data(), RITZ_MAXK * sizeof(double), hipMemcpyHostToDevice, st));
+    for (int j0 = 0; j0 < m; j0 += AI_SLAB_VECS) {
+      hipLaunchKernelGGL(k_ritz_multi, dim3(lzc.n), dim3(AI_BLOCK), 0, st, lzc.d.p, kk, (const double*)coefT.p, (const double*)cuv.p, u1.p,
+                         (const double*)slabs[(size_t)j0 / AI_SLAB_VECS], slab_stride, j0, AI_SLAB_VECS, m, j0 == 0 ? 1 : 0, out, out_stride);
+      AI_KERNEL_CHECK();
+    }
+    AI_HIP(hipStreamSynchronize(st));
+    return AI_OK;
+  }
+
   // min/max, bins, 10 costs, decision -> host vectors (raw = 1: ev used as given)
   int sweep(double T, int raw, std::vector<int32_t>& h_split, std::vector<int32_t>& h_ntrue, std::vector<double>& h_mcut) {
     const int S_ = S();
@@ -2030,5 +2419,90 @@ extern "C" int ai_bench_spmv(ai_ctx* ctx, const ai_csr* csr, int32_t reps, doubl
     const double N = (double)csr->n, E = (double)csr->nnz;
     *bytes_per_launch = E * 12.0 + (N + 1.0) * 4.0 + N * 8.0 * 3.0;
   }
+  return AI_OK;
+}
+
+extern "C" int ai_eigs_smallest(ai_ctx* ctx, const ai_csr* csr, int32_t k, const ai_ncut_opts* opts, double* evals, double* evecs,
+                                int32_t* iters, double* max_resid) {
+  if (!ctx || !csr || !evals || !evecs || k < 1 || k > RITZ_MAXK || k > csr->n) {
+    ai_set_error("ai_eigs_smallest: bad argument (1 <= k <= %d, k <= n)", RITZ_MAXK);
+    return AI_ERR_BAD_ARG;
+  }
+  AI_HIP(hipSetDevice(ctx->device));
+  ArenaScope arena_scope(&ctx->arena);
+  Solver S(ctx, csr);
+  fill_opts(S, opts);
+  const int n = (int)csr->n;
+  AI_TRY(S.begin(true));
+  AI_TRY(S.build_tasks());
+  AI_TRY(S.prepare(true));
+  hipStream_t st = ctx->stream;
+  // component structure and degrees on the host: every component contributes the eigenvalue 0
+  // with eigenvector D^1/2 1_C / sqrt(vol_C)
+  std::vector<int32_t> h_parent(n), h_orig(n);
+  std::vector<double> h_deg(n);
+  AI_HIP(hipMemcpyAsync(h_parent.data(), S.parent, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  AI_HIP(hipMemcpyAsync(h_orig.data(), S.orig, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  AI_HIP(hipMemcpyAsync(h_deg.data(), S.deg.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+  AI_HIP(hipStreamSynchronize(st));
+  std::vector<int32_t> roots;
+  for (int i = 0; i < n; ++i)
+    if (h_parent[i] == i) roots.push_back(i);
+  const int ncomp = (int)roots.size();
+  memset(evecs, 0, (size_t)k * n * sizeof(double));
+  if (iters) *iters = 0;
+  if (max_resid) *max_resid = 0.0;
+  if (ncomp >= k) {
+    // the k smallest eigenvalues are all 0: the first k components in row order span a valid answer
+    std::vector<int32_t> rank(n, -1);
+    std::vector<double> vol(k, 0.0);
+    for (int c = 0; c < k; ++c) rank[roots[c]] = c;
+    for (int i = 0; i < n; ++i) {
+      const int c = rank[h_parent[i]];
+      if (c >= 0) vol[c] += h_deg[i];
+    }
+    for (int i = 0; i < n; ++i) {
+      const int c = rank[h_parent[i]];
+      if (c >= 0) evecs[(size_t)c * n + h_orig[i]] = sqrt(h_deg[i] / vol[c]);
+    }
+    for (int c = 0; c < k; ++c) evals[c] = 0.0;
+    return AI_OK;
+  }
+  if (ncomp != 1) {
+    ai_set_error("ai_eigs_smallest: the graph has %d connected components with 1 < components < k = %d; pass one component at a time "
+                 "(every component adds a zero eigenvalue; the rest of the spectrum is the union of the components' spectra)", ncomp, k);
+    return AI_ERR_BAD_ARG;
+  }
+  // connected: eigenvalue 0 with u1, then the k - 1 largest Ritz pairs of the deflated M
+  double vol = 0.0;
+  for (int i = 0; i < n; ++i) vol += h_deg[i];
+  for (int i = 0; i < n; ++i) evecs[h_orig[i]] = sqrt(h_deg[i] / vol);
+  evals[0] = 0.0;
+  if (k == 1) return AI_OK;
+  DevBuf<double> out;
+  AI_TRY(out.alloc((size_t)(k - 1) * n));
+  std::vector<double> thetas, resids;
+  int steps = 0;
+  AI_TRY(S.lanczos_fro(k - 1, thetas, resids, out.p, (size_t)n, &steps));
+  if ((int)thetas.size() < k - 1) {
+    ai_set_error("ai_eigs_smallest: only %zu of %d eigenpairs could be formed", thetas.size() + 1, k);
+    return AI_ERR_NO_CONVERGENCE;
+  }
+  std::vector<double> h_out((size_t)(k - 1) * n);
+  AI_HIP(hipMemcpyAsync(h_out.data(), out.p, h_out.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  AI_HIP(hipStreamSynchronize(st));
+  double mr = 0.0;
+  for (int i = 0; i < k - 1; ++i) {
+    evals[i + 1] = 1.0 - thetas[i];
+    mr = std::max(mr, resids[i]);
+    const double* src = &h_out[(size_t)i * n];
+    double* dst = evecs + (size_t)(i + 1) * n;
+    double n2 = 0.0;
+    for (int r = 0; r < n; ++r) n2 += src[r] * src[r];
+    const double rn = 1.0 / sqrt(n2);
+    for (int r = 0; r < n; ++r) dst[h_orig[r]] = src[r] * rn;
+  }
+  if (iters) *iters = steps;
+  if (max_resid) *max_resid = mr;
   return AI_OK;
 }

@@ -275,6 +275,17 @@ def lsym_apply(graph: DeviceGraph, x):
     return y
 
 
+def eigs_smallest(graph: DeviceGraph, k: int, *, tol=None, max_iter=None, check_every=None):
+    """k smallest eigenpairs of L_sym (``ai_eigs_smallest``): (evals[k], evecs[n, k], steps, max residual)."""
+    evals = np.empty(k, dtype=np.float64)
+    vecs = np.empty((k, graph.n), dtype=np.float64)
+    it, mr = C.c_int32(), C.c_double()
+    o = _opts(tol, max_iter, check_every)
+    _ffi.check(_ffi.load().ai_eigs_smallest(graph.ctx._h, graph._h, int(k), C.byref(o), evals.ctypes.data, vecs.ctypes.data,
+                                            C.byref(it), C.byref(mr)), "ai_eigs_smallest")
+    return evals, vecs.T, int(it.value), float(mr.value)
+
+
 def bench_spmv(graph: DeviceGraph, reps=50):
     """(average kernel ms, algorithmic bytes per launch) of the fused Lanczos SpMV kernel."""
     ms, by = C.c_double(), C.c_double()

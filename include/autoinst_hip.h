@@ -135,6 +135,36 @@ int ai_sweep(ai_ctx* ctx, const ai_csr* csr, const double* ev, double* costs, ui
 int ai_lsym_apply(ai_ctx* ctx, const ai_csr* csr, const double* x, double* y);
 
 /*
+ * k smallest eigenpairs of L_sym = D^-1/2 (D - W) D^-1/2, W = w + I (BASELINE.json configs[4]; the
+ * reference itself only ever asks for k = 2, normalized_cut.py:49).  1 <= k <= 64.
+ * evals[k] ascending; evecs[j * n + i] = component i (caller's original order) of unit vector j.
+ * Every connected component contributes one zero eigenvalue with eigenvector D^1/2 1_C / sqrt(vol_C)
+ * (formed explicitly).  With >= k components the answer is k such pairs (any k of them are a
+ * valid answer, as with SciPy); a connected graph gets Lanczos with full re-orthogonalisation for
+ * the other k - 1 pairs (stops when the innermost pair's Ritz residual <= opts->tol).
+ * 1 < components < k is AI_ERR_BAD_ARG: pass one component at a time.
+ */
+int ai_eigs_smallest(ai_ctx* ctx, const ai_csr* csr, int32_t k, const ai_ncut_opts* opts, double* evals,
+                     double* evecs, int32_t* iters, double* max_resid);
+
+/*
+ * "Next" rows on either side of the hot path.
+ *
+ * ai_radius_mean_pool: pipeline/utils/point_cloud/chunk_generation.py:243-256 -- out[i] (dim float64) =
+ *   mean of the float32 feature rows of all source points with distance < radius from query i (a zero
+ *   row when there is none); count_out[i] (may be NULL) = how many.  dim <= 384.
+ * ai_nn1_project: pipeline/utils/point_cloud/point_cloud_utils.py:144-174 (kDTree_1NN_feature_reprojection)
+ *   -- nn_index[i] = index of the source point nearest to fine point i, nn_dist[i] (may be NULL) its
+ *   distance; the caller gathers labels / colours and applies max_radius.
+ * Buffers are host or device according to mem_kind (all of one kind).
+ */
+int ai_radius_mean_pool(ai_ctx* ctx, const double* query_xyz, int64_t nq, const double* src_xyz, int64_t ns,
+                        const float* src_feat, int32_t dim, double radius, int mem_kind, double* out,
+                        int32_t* count_out);
+int ai_nn1_project(ai_ctx* ctx, const double* to_xyz, int64_t nt, const double* from_xyz, int64_t nf,
+                   int mem_kind, int32_t* nn_index, double* nn_dist);
+
+/*
  * Timing hook for bench.py: runs `reps` fused Lanczos SpMV steps on the whole graph as
  * one segment and returns the average kernel time (HIP events on the context's stream)
  * plus the algorithmic byte count of one launch.

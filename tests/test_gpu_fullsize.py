@@ -76,3 +76,77 @@ def test_50k_largest_component_eigen_residual(api):
     assert resid <= 1e-10
     assert np.linalg.norm(L @ ev - lam * ev) <= 1e-8
     assert 0 < lam < 0.1
+
+
+def test_cfg4_trimodal_50k_matches_oracle(api):
+    """BASELINE configs[3] at a size the oracle finishes quickly: TARL + Spatial + DINOv2 (384-d)."""
+    from autoinst_amd import synth
+    ch = synth.synthetic_chunk(50_000, seed=2, tarl=True, dino=True)
+    cfg = dict(alpha=1.0, theta=0.5, gamma=0.1)
+    A = api.get_affinity_matrix(ch["points"], ch["tarl"], ch["dino"], **cfg)
+    B = ncuts_ref.affinity_sparse(ch["points"], ch["tarl"], ch["dino"], **cfg)
+    assert np.array_equal(A.indptr, B.indptr) and np.array_equal(A.indices, B.indices)
+    assert (np.abs(A.data - B.data) / B.data).max() <= 1e-12
+    assert abs(A - A.T).max() == 0.0
+    n = A.shape[0]
+    got = ncuts_ref.groups_to_labels(api.ncuts(ch["points"], ch["tarl"], ch["dino"], T=0.005, **cfg), n)
+    ref = ncuts_ref.groups_to_labels(ncuts_ref.normalized_cut(B, n, np.arange(n), T=0.005, fast=True), n)
+    assert api.last_stats()["unconverged"] == 0
+    assert ncuts_ref.adjusted_rand_index(got, ref) >= 0.98
+
+
+def test_cfg3_small_map_chunk_parallel_driver(api):
+    """The cfg3 driver on one GPU with a reduced map: every chunk's labels equal a plain run."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import run_cfg3
+    from autoinst_amd import synth
+    sizes = run_cfg3.chunk_sizes(True)
+    merged, _ = run_cfg3.run_map(sizes, 1, 0, 0, in_flight=3)
+    assert sorted(merged) == list(range(len(sizes)))
+    for i in (0, len(sizes) - 1):
+        ch = synth.synthetic_chunk(sizes[i], seed=1000 + i, tarl=True)
+        g = api.build_affinity(ch["points"], ch["tarl"], alpha=1.0, theta=0.5, gamma=0.0)
+        lab, ng, _ = api.ncuts_labels(g, sizes[i], 0.03)
+        assert np.array_equal(lab, merged[i])
+
+
+def _largest_component(api, n, seed):
+    from autoinst_amd import synth
+    pts, _ = synth.surface_chunk(n, seed=seed)
+    A = api.get_affinity_matrix(pts, alpha=1.0, theta=0.0, gamma=0.0)
+    _, comp = connected_components(A, directed=False)
+    idx = np.flatnonzero(comp == np.bincount(comp).argmax())
+    return A, sp.csr_matrix(A[idx][:, idx])
+
+
+@pytest.mark.parametrize("k", [8, 64])
+def test_cfg5_eigs_smallest_connected_vs_scipy(api, k):
+    """BASELINE configs[4] (k = 64 eigenpairs) at a size SciPy's shift-invert solves quickly."""
+    import scipy.sparse.linalg as spla
+    _, sub = _largest_component(api, 30_000, 4)
+    n = sub.shape[0]
+    assert n > 2000
+    g = api.DeviceGraph.from_scipy(sub)
+    evals, V, steps, resid = api.eigs_smallest(g, k, tol=1e-9)
+    L, _ = ncuts_ref.laplacian_sym(sub)
+    ref = np.sort(spla.eigsh(L, k, sigma=-1e-2, which="LM")[0])
+    assert resid <= 1e-8, (resid, steps)
+    assert np.all(np.diff(evals) >= -1e-12) and abs(evals[0]) <= 1e-12
+    assert np.abs(evals - ref).max() <= 1e-8, np.abs(evals - ref).max()
+    R = L @ V - V * evals[None, :]
+    assert np.linalg.norm(R, axis=0).max() <= 1e-7
+    assert np.abs(V.T @ V - np.eye(k)).max() <= 1e-8
+
+
+def test_cfg5_eigs_smallest_disconnected_is_the_null_space(api):
+    A, _ = _largest_component(api, 30_000, 4)
+    ncomp, _ = connected_components(A, directed=False)
+    k = min(16, ncomp)
+    assert k >= 2
+    g = api.DeviceGraph.from_scipy(A)
+    evals, V, _, _ = api.eigs_smallest(g, k)
+    L, _ = ncuts_ref.laplacian_sym(A)
+    assert np.all(evals == 0.0)
+    assert np.abs(L @ V).max() <= 1e-13
+    assert np.abs(V.T @ V - np.eye(k)).max() <= 1e-12

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[2]: a whole map's chunks, chunk-parallel across the GPUs of one node.
+
+The sample map is not available offline, so the map is synthetic: 64 chunks with
+the real size distribution N ~ logU(3k, 30k) plus 8 chunks of 200k points, TARL+Spatial.
+Launch with one rank per GPU:
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/run_cfg3.py
+    python tools/run_cfg3.py --small            # 1 GPU, reduced map (used by the GPU test suite)
+
+Chunks are assigned by LPT (autoinst_amd.sharding), each rank keeps `--in-flight` chunks going,
+label arrays are gathered to rank 0 (RCCL), which prints one JSON line.
+"""
+import argparse, json, os, sys, time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def chunk_sizes(small: bool):
+    rng = np.random.default_rng(3)
+    if small:
+        return [int(x) for x in np.exp(rng.uniform(np.log(3000), np.log(12000), 6))] + [40_000]
+    return [int(x) for x in np.exp(rng.uniform(np.log(3000), np.log(30000), 64))] + [200_000] * 8
+
+
+def run_map(sizes, world, rank, local_rank, in_flight=4, dist=None, dev=None):
+    from autoinst_amd import ncuts_api as api, sharding, synth
+    mine = sharding.lpt_assign(sizes, world)[rank]
+    ctxs = [api.Context(local_rank) for _ in range(in_flight)]
+    data = {i: synth.synthetic_chunk(sizes[i], seed=1000 + i, tarl=True) for i in mine}
+
+    def work(job):
+        slot, i = job
+        ch = data[i]
+        groups_lab, ng, st = None, None, None
+        g = api.build_affinity(ch["points"], ch["tarl"], alpha=1.0, theta=0.5, gamma=0.0, ctx=ctxs[slot])
+        try:
+            lab, ng, st = api.ncuts_labels(g, sizes[i], 0.03)
+        finally:
+            g.free()
+        return i, lab
+
+    # largest first; slot = position modulo the number of contexts (a context serves one chunk at a time)
+    order = sorted(mine, key=lambda i: -sizes[i])
+    t0 = time.perf_counter()
+    out = {}
+    with ThreadPoolExecutor(max_workers=in_flight) as pool:
+        lanes = [order[k::in_flight] for k in range(in_flight)]
+        def lane(k):
+            return [work((k, i)) for i in lanes[k]]
+        for res in pool.map(lane, range(in_flight)):
+            for i, lab in res:
+                out[i] = lab
+    merged = sharding.gather_labels(out, device=dev)
+    return merged, time.perf_counter() - t0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--small", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=4)
+    args = ap.parse_args()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    sizes = chunk_sizes(args.small)
+    merged, dt = run_map(sizes, world, rank, local, args.in_flight, dist, dev)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+    if rank == 0:
+        assert sorted(merged) == list(range(len(sizes))) and all(merged[i].shape[0] == sizes[i] for i in merged)
+        print(json.dumps({"config": "cfg3 synthetic map", "chunks": len(sizes), "points": int(sum(sizes)), "n_gpus": world,
+                          "seconds": dt, "chunks_per_s": len(sizes) / dt, "points_per_s": sum(sizes) / dt,
+                          "groups_total": int(sum(int(m.max()) + 1 for m in merged.values()))}), flush=True)
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
