@@ -307,7 +307,8 @@ __global__ __launch_bounds__(AI_BLOCK) void k_lz_init(const Task* __restrict__ c
 // 16 lanes per row (neighbour counts ~30-40) read 64-B / 128-B runs of col / wm; each lane group
 // keeps AI_ROW_ILP rows in flight so that the dependent chain rowptr -> col -> gather is overlapped
 // four deep; gathers of R_j are served by L2 / MALL.
-__global__ __launch_bounds__(AI_BLOCK) void k_lz_spmv(const Task* __restrict__ ftasks, const int32_t* __restrict__ factive, int ntask,
+template <int LPR, int ILP>
+__global__ __launch_bounds__(AI_BLOCK) void k_lz_spmv_t(const Task* __restrict__ ftasks, const int32_t* __restrict__ factive, int ntask,
                                                       const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                       const double* __restrict__ wm, const double* __restrict__ sinv2,
                                                       const double* __restrict__ Rj, double* __restrict__ Z,
@@ -317,13 +318,14 @@ __global__ __launch_bounds__(AI_BLOCK) void k_lz_spmv(const Task* __restrict__ f
   const int act = factive[t];
   const Task tk = ftasks[t];  // independent of the flag: both loads are in flight together
   if (!act) return;
-  const int l = threadIdx.x & (AI_LPR - 1), r = threadIdx.x / AI_LPR;
-  int p0[AI_ROW_ILP], p1[AI_ROW_ILP];
-  double sum[AI_ROW_ILP], ri[AI_ROW_ILP], s2[AI_ROW_ILP];
+  const int l = threadIdx.x & (LPR - 1), r = threadIdx.x / LPR;
+  constexpr int GROUPS = AI_BLOCK / LPR;
+  int p0[ILP], p1[ILP];
+  double sum[ILP], ri[ILP], s2[ILP];
   int len = 0;
 #pragma unroll
-  for (int u = 0; u < AI_ROW_ILP; ++u) {
-    const int row = tk.x + r + u * (AI_BLOCK / AI_LPR);
+  for (int u = 0; u < ILP; ++u) {
+    const int row = tk.x + r + u * GROUPS;
     const bool ok = row < tk.y;
     p0[u] = ok ? rowptr[row] : 0;
     p1[u] = ok ? rowptr[row + 1] : 0;
@@ -333,26 +335,28 @@ __global__ __launch_bounds__(AI_BLOCK) void k_lz_spmv(const Task* __restrict__ f
     sum[u] = 0.0;
   }
 #pragma unroll
-  for (int u = 0; u < AI_ROW_ILP; ++u) len = max(len, p1[u] - p0[u]);
-  for (int k = l; k < len; k += AI_LPR) {
-    int c[AI_ROW_ILP];
-    double w[AI_ROW_ILP];
+  for (int u = 0; u < ILP; ++u) len = max(len, p1[u] - p0[u]);
+  for (int k = l; k < len; k += LPR) {
+    int c[ILP];
+    double w[ILP];
 #pragma unroll
-    for (int u = 0; u < AI_ROW_ILP; ++u) {
+    for (int u = 0; u < ILP; ++u) {
       const int p = p0[u] + k;
       const bool ok = p < p1[u];
       c[u] = ok ? col[p] : -1;
       w[u] = ok ? wm[p] : 0.0;
     }
 #pragma unroll
-    for (int u = 0; u < AI_ROW_ILP; ++u)
+    for (int u = 0; u < ILP; ++u)
       if (c[u] >= 0) sum[u] = fma(w[u], Rj[c[u]], sum[u]);
   }
   double acc = 0.0;
 #pragma unroll
-  for (int u = 0; u < AI_ROW_ILP; ++u) {
-    const double sg = ai_group16_sum(sum[u]);
-    const int row = tk.x + r + u * (AI_BLOCK / AI_LPR);
+  for (int u = 0; u < ILP; ++u) {
+    double sg = sum[u];
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) sg += __shfl_xor(sg, o, LPR);
+    const int row = tk.x + r + u * GROUPS;
     if (l == 0 && row < tk.y) {
       const double z = fma(s2[u], ri[u], sg);
       Z[row] = z;
@@ -1691,16 +1695,32 @@ class Solver {
   }
 
   // e0 / e1 (optional): HIP events that receive this dispatch's own start / stop timestamps
-  int launch_spmv(int j, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+  int spmv_variant = -1;
+  template <int LPR, int ILP>
+  int launch_spmv_t(int j, hipEvent_t e0, hipEvent_t e1) {
+    static_assert((AI_BLOCK / LPR) * ILP == AI_FINE_ROWS, "a block covers exactly one fine task");
     if (e0) {
-      hipExtLaunchKernelGGL(k_lz_spmv, dim3(lzf.n), dim3(AI_BLOCK), 0, st, e0, e1, 0, (const Task*)lzf.d.p, (const int32_t*)factive.p, lzf.n,
-                            rowptr, col, (const double*)wm.p, (const double*)sinv2.p, (const double*)vec(j), Y.p, pA.p);
+      hipExtLaunchKernelGGL((k_lz_spmv_t<LPR, ILP>), dim3(lzf.n), dim3(AI_BLOCK), 0, st, e0, e1, 0, (const Task*)lzf.d.p, (const int32_t*)factive.p,
+                            lzf.n, rowptr, col, (const double*)wm.p, (const double*)sinv2.p, (const double*)vec(j), Y.p, pA.p);
     } else {
-      hipLaunchKernelGGL(k_lz_spmv, dim3(lzf.n), dim3(AI_BLOCK), 0, st, lzf.d.p, factive.p, lzf.n, rowptr, col, wm.p, sinv2.p,
-                         (const double*)vec(j), Y.p, pA.p);
+      hipLaunchKernelGGL((k_lz_spmv_t<LPR, ILP>), dim3(lzf.n), dim3(AI_BLOCK), 0, st, (const Task*)lzf.d.p, (const int32_t*)factive.p, lzf.n,
+                         rowptr, col, (const double*)wm.p, (const double*)sinv2.p, (const double*)vec(j), Y.p, pA.p);
     }
     AI_KERNEL_CHECK();
     return AI_OK;
+  }
+  int launch_spmv(int j, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+    if (spmv_variant < 0) {
+      const char* v = getenv("AI_SPMV_VARIANT");
+      spmv_variant = v ? atoi(v) : 0;
+    }
+    switch (spmv_variant) {
+      case 1: return launch_spmv_t<8, 2>(j, e0, e1);
+      case 2: return launch_spmv_t<32, 8>(j, e0, e1);
+      case 3: return launch_spmv_t<4, 1>(j, e0, e1);
+      case 4: return launch_spmv_t<64, 16>(j, e0, e1);
+      default: return launch_spmv_t<16, 4>(j, e0, e1);
+    }
   }
 
   // Lock-step Lanczos over every mode-0 segment, then Ritz vectors into ev.
