@@ -8,7 +8,7 @@ from .config import CONFIG, CONFIG_SPATIAL, CONFIG_TARL_SPATIAL, CONFIG_TARL_SPA
 
 def __getattr__(name):
     # compute entry points load the HIP library on first use and raise if it is missing
-    if name in ("normalized_cut", "ncuts", "get_affinity_matrix", "build_affinity", "ncuts_chunk", "ncuts_labels",
+    if name in ("normalized_cut", "ncuts", "get_affinity_matrix", "build_affinity", "ncuts_chunk", "ncuts_labels", "ncuts_labels_batch",
                 "Context", "DeviceGraph", "default_context", "last_stats", "fiedler", "sweep", "lsym_apply", "bench_spmv", "eigs_smallest"):
         from . import ncuts_api as _n
         return getattr(_n, name)

@@ -20,7 +20,7 @@ SYMBOLS = (
     "ai_version", "ai_last_error", "ai_ctx_create", "ai_ctx_destroy", "ai_affinity_build",
     "ai_csr_from_host", "ai_csr_dims", "ai_csr_export", "ai_csr_free", "ai_ncut", "ai_fiedler",
     "ai_sweep", "ai_lsym_apply", "ai_bench_spmv", "ai_eigs_smallest",
-    "ai_radius_mean_pool", "ai_nn1_project",
+    "ai_radius_mean_pool", "ai_nn1_project", "ai_ncut_batch",
 )
 
 
@@ -80,6 +80,7 @@ def load():
     lib.ai_eigs_smallest.argtypes = [vp, vp, i32, P(NcutOpts), vp, vp, P(i32), P(dbl)]
     lib.ai_radius_mean_pool.argtypes = [vp, vp, i64, vp, i64, vp, i32, dbl, C.c_int, vp, vp]
     lib.ai_nn1_project.argtypes = [vp, vp, i64, vp, i64, C.c_int, vp, vp]
+    lib.ai_ncut_batch.argtypes = [vp, P(vp), i32, P(i64), dbl, dbl, P(NcutOpts), P(vp), P(i32), P(NcutStats)]
     for name in SYMBOLS:
         if name not in ("ai_version", "ai_last_error"):
             getattr(lib, name).restype = C.c_int

@@ -308,13 +308,11 @@ __global__ __launch_bounds__(AI_BLOCK) void k_lz_init(const Task* __restrict__ c
 // keeps AI_ROW_ILP rows in flight so that the dependent chain rowptr -> col -> gather is overlapped
 // four deep; gathers of R_j are served by L2 / MALL.
 template <int LPR, int ILP>
-__global__ __launch_bounds__(AI_BLOCK) void k_lz_spmv_t(const Task* __restrict__ ftasks, const int32_t* __restrict__ factive, int ntask,
-                                                      const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                                      const double* __restrict__ wm, const double* __restrict__ sinv2,
-                                                      const double* __restrict__ Rj, double* __restrict__ Z,
-                                                      double* __restrict__ pA) {
-  __shared__ double sm[AI_BLOCK / 64];
-  const int t = ai_xcd_task(blockIdx.x, ntask);
+__device__ __forceinline__ void spmv_body(int t, const Task* __restrict__ ftasks, const int32_t* __restrict__ factive,
+                                          const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                          const double* __restrict__ wm, const double* __restrict__ sinv2,
+                                          const double* __restrict__ Rj, double* __restrict__ Z, double* __restrict__ pA,
+                                          double* sm) {
   const int act = factive[t];
   const Task tk = ftasks[t];  // independent of the flag: both loads are in flight together
   if (!act) return;
@@ -367,6 +365,16 @@ __global__ __launch_bounds__(AI_BLOCK) void k_lz_spmv_t(const Task* __restrict__
   if (threadIdx.x == 0) pA[t] = tot;
 }
 
+template <int LPR, int ILP>
+__global__ __launch_bounds__(AI_BLOCK) void k_lz_spmv_t(const Task* __restrict__ ftasks, const int32_t* __restrict__ factive, int ntask,
+                                                      const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                      const double* __restrict__ wm, const double* __restrict__ sinv2,
+                                                      const double* __restrict__ Rj, double* __restrict__ Z,
+                                                      double* __restrict__ pA) {
+  __shared__ double sm[AI_BLOCK / 64];
+  spmv_body<LPR, ILP>(ai_xcd_task(blockIdx.x, ntask), ftasks, factive, rowptr, col, wm, sinv2, Rj, Z, pA, sm);
+}
+
 struct LzSeg {
   int32_t* frozen;      // [S]
   int32_t* m;           // [S] size of T at freeze
@@ -393,19 +401,19 @@ __device__ __forceinline__ void lz_freeze(const LzSeg& L, int s, int m, TaskRang
 // then  R_{j+1} = y - alpha_j v_j - b_j v_{j-1},  y = (z - g_j u1) / b_j,
 // and the partials (R.R, u1.R) of R_{j+1}.  The segment's first block records alpha_j, b_j, g_j.
 // A vanishing b_j (Krylov space exhausted) freezes the segment with T of size j.
-__global__ __launch_bounds__(AI_BLOCK) void k_lz_update(const Task* __restrict__ ctasks, const TaskRange* __restrict__ cranges,
-                                                        LzSeg L, int j, const double* __restrict__ pA,
-                                                        const double2* __restrict__ pBcur, double2* __restrict__ pBnext,
-                                                        const double* __restrict__ u1, const double* __restrict__ Z,
-                                                        const double* __restrict__ Rj, const double* __restrict__ Rjm1,
-                                                        double* __restrict__ Rnext) {
+__device__ __forceinline__ void update_body(int bid, const Task* __restrict__ ctasks, const TaskRange* __restrict__ cranges,
+                                            const LzSeg& L, int j, const double* __restrict__ pA,
+                                            const double2* __restrict__ pBcur, double2* __restrict__ pBnext,
+                                            const double* __restrict__ u1, const double* __restrict__ Z,
+                                            const double* __restrict__ Rj, const double* __restrict__ Rjm1,
+                                            double* __restrict__ Rnext, double (*sm3)[AI_BLOCK / 64]) {
   constexpr int RPT = AI_COARSE_ROWS / AI_BLOCK;  // rows per thread
-  __shared__ double sm3[3][AI_BLOCK / 64];
-  const int act = L.cactive[blockIdx.x];
-  const Task tk = ctasks[blockIdx.x];
-  const TaskRange rg = cranges[blockIdx.x];
+  const int act = L.cactive[bid];
+  const Task tk = ctasks[bid];
+  const TaskRange rg = cranges[bid];
   if (!act) return;
   const int s = tk.z;
+  if (j >= (tk.w >> 1)) return;  // the segment's Krylov space is exhausted at its own dimension
   // row data does not depend on the segment scalars: get it moving before the reductions
   double zr[RPT], rr[RPT], rm[RPT], ur[RPT];
 #pragma unroll
@@ -453,12 +461,12 @@ __global__ __launch_bounds__(AI_BLOCK) void k_lz_update(const Task* __restrict__
   __syncthreads();
   const double b = sqrt(fmax(nn - g * g, 0.0));  // ||R_j - g u1||, u1 has unit norm
   if (j > 0 && !(b > 1e-14)) {
-    if (tk.w) lz_freeze(L, s, j, rg, threadIdx.x, AI_BLOCK);
+    if (tk.w & 1) lz_freeze(L, s, j, rg, threadIdx.x, AI_BLOCK);
     return;
   }
   const double rb = 1.0 / b;
   const double al = rb * rb * (a - g * g);
-  if (tk.w && threadIdx.x == 0) {
+  if ((tk.w & 1) && threadIdx.x == 0) {
     L.alpha_hist[(size_t)s * L.mcap + j] = al;
     L.b_hist[(size_t)s * (L.mcap + 1) + j] = b;
     L.g_hist[(size_t)s * (L.mcap + 1) + j] = g;
@@ -492,8 +500,71 @@ __global__ __launch_bounds__(AI_BLOCK) void k_lz_update(const Task* __restrict__
       tn += sm3[0][i];
       tg += sm3[1][i];
     }
-    pBnext[blockIdx.x] = make_double2(tn, tg);
+    pBnext[bid] = make_double2(tn, tg);
   }
+}
+
+__global__ __launch_bounds__(AI_BLOCK) void k_lz_update(const Task* __restrict__ ctasks, const TaskRange* __restrict__ cranges,
+                                                        LzSeg L, int j, const double* __restrict__ pA,
+                                                        const double2* __restrict__ pBcur, double2* __restrict__ pBnext,
+                                                        const double* __restrict__ u1, const double* __restrict__ Z,
+                                                        const double* __restrict__ Rj, const double* __restrict__ Rjm1,
+                                                        double* __restrict__ Rnext) {
+  __shared__ double sm3[3][AI_BLOCK / 64];
+  update_body(blockIdx.x, ctasks, cranges, L, j, pA, pBcur, pBnext, u1, Z, Rj, Rjm1, Rnext, sm3);
+}
+
+// ---- graph-replayable forms: every level-specific value comes from one device-resident block, and
+// the step index from two device counters, so that ONE instantiated hipGraph of AI_GRAPH_STEPS steps
+// serves every level of every chunk (one API call per 16 steps instead of 32 launches).
+#define AI_GRAPH_STEPS 16
+struct LzArgs {
+  const Task* ftasks;
+  const Task* ctasks;
+  const TaskRange* cranges;
+  const TaskRange* segrange;
+  const int32_t* mode;
+  const int32_t* rowptr;
+  const int32_t* col;
+  const double* wm;
+  const double* sinv2;
+  const double* u1;
+  double* Z;
+  double* pA;
+  double2* pB0;
+  double2* pB1;
+  double* const* slabs;
+  double* bnew;  // [AI_CHECK_DEPTH][S + 1]
+  int32_t* step;  // [0]: step of the next SpMV, [1]: step of the next update
+  size_t stride;
+  LzSeg L;
+  int nft, nct, S;
+};
+
+__global__ __launch_bounds__(AI_BLOCK) void k_lz_spmv_g(const LzArgs* __restrict__ A) {
+  __shared__ double sm[AI_BLOCK / 64];
+  const int j = A->step[0];
+  if (blockIdx.x == 0 && threadIdx.x == 0) A->step[1] = j;  // nobody reads step[1] during this launch
+  const int nft = A->nft;
+  if (j >= A->L.mcap || (int)blockIdx.x >= nft) return;
+  const double* Rj = A->slabs[j / AI_SLAB_VECS] + (size_t)(j % AI_SLAB_VECS) * A->stride;
+  spmv_body<16, 4>(ai_xcd_task(blockIdx.x, nft), A->ftasks, A->L.factive, A->rowptr, A->col, A->wm, A->sinv2, Rj, A->Z, A->pA, sm);
+}
+
+__global__ __launch_bounds__(AI_BLOCK) void k_lz_update_g(const LzArgs* __restrict__ A) {
+  __shared__ double sm3[3][AI_BLOCK / 64];
+  const int j = A->step[1];
+  if (blockIdx.x == 0 && threadIdx.x == 0) A->step[0] = j + 1;  // nobody reads step[0] during this launch
+  if (j >= A->L.mcap || (int)blockIdx.x >= A->nct) return;
+  const size_t st = A->stride;
+  double* const* sl = A->slabs;
+  const double* Rj = sl[j / AI_SLAB_VECS] + (size_t)(j % AI_SLAB_VECS) * st;
+  const int jm = j > 0 ? j - 1 : 0;
+  const double* Rjm1 = sl[jm / AI_SLAB_VECS] + (size_t)(jm % AI_SLAB_VECS) * st;
+  double* Rn = sl[(j + 1) / AI_SLAB_VECS] + (size_t)((j + 1) % AI_SLAB_VECS) * st;
+  const double2* pBcur = (j & 1) ? A->pB1 : A->pB0;
+  double2* pBnext = (j & 1) ? A->pB0 : A->pB1;
+  update_body(blockIdx.x, A->ctasks, A->cranges, A->L, j, A->pA, pBcur, pBnext, A->u1, A->Z, Rj, Rjm1, Rn, sm3);
 }
 
 // Number of eigenvalues of T_m (diag a[0..m), squared off-diagonals bb[1..m), both in LDS) that
@@ -538,6 +609,27 @@ __global__ __launch_bounds__(64) void k_lz_bnew(const TaskRange* __restrict__ se
   if (threadIdx.x == 0) bnew_out[s] = sqrt(fmax(nn - gg * gg, 0.0));
 }
 
+// graph form: m = the device step counter after the batch; the output slot rotates with the batch number
+__global__ __launch_bounds__(64) void k_lz_bnew_g(const LzArgs* __restrict__ A) {
+  const int s = blockIdx.x;
+  if (s >= A->S) return;
+  if (A->mode[s] != 0 || A->L.frozen[s]) return;
+  const int mraw = A->step[0];
+  const int m = min(mraw, A->L.mcap);
+  const double2* pB = (m & 1) ? A->pB1 : A->pB0;
+  double* out = A->bnew + (size_t)((mraw / AI_GRAPH_STEPS) % AI_CHECK_DEPTH) * (A->S + 1);
+  const TaskRange rg = A->segrange[s];
+  double nn = 0.0, gg = 0.0;
+  for (int t = rg.z + threadIdx.x; t < rg.w; t += 64) {
+    const double2 v = pB[t];
+    nn += v.x;
+    gg += v.y;
+  }
+  nn = ai_wave_sum(nn);
+  gg = ai_wave_sum(gg);
+  if (threadIdx.x == 0) out[s] = sqrt(fmax(nn - gg * gg, 0.0));
+}
+
 // Convergence check after step j (m = j + 1 rows of T), one wave per running segment, on the side
 // stream: top eigenvalue of T_m by 64-way multisection; |s_m| by the recurrence from the bottom
 // row upwards (the growing, hence stable, direction); residual = b_m |s_m|.  Freezes the segment
@@ -562,6 +654,9 @@ __global__ __launch_bounds__(64) void k_lz_check(const int32_t* __restrict__ seg
   const double bnew = bnew_in[s];
   const double* bh = L.b_hist + (size_t)s * (L.mcap + 1);
   const double* ah = L.alpha_hist + (size_t)s * L.mcap;
+  const int cap = min(min(ns - 1, max_iter), L.mcap);
+  const bool last = (m >= cap) || !(bnew > 1e-14);
+  m = min(m, cap);  // steps launched past the segment's cap did nothing (graph replay works in batches)
   // T_m into LDS: a[0..m), b^2[0..m) (b^2[0] unused)
   extern __shared__ double lds[];
   double* la = lds;
@@ -572,8 +667,6 @@ __global__ __launch_bounds__(64) void k_lz_check(const int32_t* __restrict__ seg
     lbb[i] = bi * bi;
   }
   __syncthreads();
-  const int cap = min(min(ns - 1, max_iter), L.mcap);
-  const bool last = (m >= cap) || !(bnew > 1e-14);
   // ---- top eigenvalue of T_m: lambda_max >= max diagonal, <= Gershgorin bound
   double lo = -1e300, hi = -1e300;
   for (int i = lane; i < m; i += 64) {
@@ -1119,6 +1212,12 @@ __global__ __launch_bounds__(AI_BLOCK) void k_lsym_apply(const int32_t* __restri
   if (l == 0) y[row] = x[row] - fma(sinv2[row], x[row], sum);
 }
 
+// dst[i] = src[i] + add (src == nullptr: dst[i] = i + add): concatenation of several CSR graphs
+__global__ __launch_bounds__(AI_BLOCK) void k_offset_copy(int32_t* __restrict__ dst, const int32_t* __restrict__ src, int64_t n,
+                                                          int32_t add) {
+  const int64_t i = (int64_t)blockIdx.x * AI_BLOCK + threadIdx.x;
+  if (i < n) dst[i] = (src ? src[i] : (int32_t)i) + add;
+}
 __global__ __launch_bounds__(AI_BLOCK) void k_iota(int32_t* __restrict__ a, int32_t n) {
   const int i = blockIdx.x * AI_BLOCK + threadIdx.x;
   if (i < n) a[i] = i;
@@ -1322,6 +1421,7 @@ struct SegHost {
   int start, n, gstart;
   int mode;     // 0 Lanczos, 1 null vector
   int need_cc;  // 0: component labels were carried over a cut between whole components
+  int chunk;    // which chunk of a batched call the segment belongs to
 };
 
 static double now_ms() {
@@ -1531,7 +1631,7 @@ class Solver {
     AI_HIP(hipMemcpyAsync(final_order.p, orig, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     na = n;
     segs.clear();
-    if (force_single_segment) segs.push_back(SegHost{0, n, 0, 0, 1});
+    if (force_single_segment) segs.push_back(SegHost{0, n, 0, 0, 1, 0});
     return AI_OK;
   }
 
@@ -1550,6 +1650,8 @@ class Solver {
         t.y = std::min(lo + rows_per_task, segs[s].start + segs[s].n);
         t.z = s;
         t.w = first ? 1 : 0;
+        // Lanczos lists: bits 1.. carry the segment's step cap (its Krylov dimension / the step limit)
+        if (lanczos_only) t.w |= std::max(1, std::min(opt.max_iter, segs[s].n - 1)) << 1;
         first = false;
         tl.h.push_back(t);
       }
@@ -1636,7 +1738,7 @@ class Solver {
     AI_TRY(pA.ensure(lzf.n + 1));
     AI_TRY(pB[0].ensure(lzc.n + 1));
     AI_TRY(pB[1].ensure(lzc.n + 1));
-    Pack pk(ctx->stage + AI_STAGE_BYTES / 4, AI_STAGE_BYTES / 4);
+    Pack pk(ctx->stage + AI_STAGE_BYTES / 4, AI_STAGE_BYTES / 4 - 16384);  // the tail holds the slab table and LzArgs
     pk.add(&s_mode.p, mode.data(), (size_t)S_ + 1);
     pk.add(&segrange.p, h_segrange.data(), (size_t)S_ + 1);
     pk.add(&lzf.d.p, lzf.h.data(), (size_t)lzf.n);
@@ -1767,14 +1869,14 @@ class Solver {
     // blocks exit at their activity flag, so steps launched past the end cost next to nothing;
     // the host still never runs more than AI_RUNAHEAD steps past an unread check.
     const int AI_RUNAHEAD = 6;
-    struct Pending { int slot, m; };
+    struct Pending { int slot, m, ev; };
     std::vector<Pending> pending;  // FIFO of in-flight checks
     size_t phead = 0;
     bool done = false;
     auto reap = [&](bool block) -> int {
       while (phead < pending.size()) {
         const Pending pc = pending[phead];
-        hipEvent_t e = ctx->chk_ev[pc.slot % AI_CHECK_DEPTH];
+        hipEvent_t e = ctx->chk_ev[pc.ev];
         if (block) {
           AI_HIP(hipEventSynchronize(e));
         } else {
@@ -1788,7 +1890,68 @@ class Solver {
       }
       return AI_OK;
     };
-    for (int j = 0; j < mcap && !done; ++j) {
+    hipGraphExec_t gexec = nullptr;
+    // opt-in: measured slower than plain launches on MI355X (replay floor + power-of-two grids), kept for experiments
+    bool use_graph = !dense_checks && !time_spmv && S_ <= 128 && getenv("AI_USE_GRAPH") != nullptr;
+    if (use_graph && lz_graph(lzf.n, lzc.n, &gexec) != AI_OK) use_graph = false;
+    if (use_graph) {
+      // level constants -> the device block the graph kernels read
+      LzArgs* ha = (LzArgs*)(ctx->stage + AI_STAGE_BYTES / 2 - 4096);
+      AI_TRY(sync_slabtab());
+      ha->ftasks = lzf.d.p;
+      ha->ctasks = lzc.d.p;
+      ha->cranges = cranges.p;
+      ha->segrange = segrange.p;
+      ha->mode = s_mode.p;
+      ha->rowptr = rowptr;
+      ha->col = col;
+      ha->wm = wm.p;
+      ha->sinv2 = sinv2.p;
+      ha->u1 = u1.p;
+      ha->Z = Y.p;
+      ha->pA = pA.p;
+      ha->pB0 = pB[0].p;
+      ha->pB1 = pB[1].p;
+      ha->slabs = d_slabtab.p;
+      ha->bnew = bnew_buf.p;
+      ha->step = ctx->lz_step_dev;
+      ha->stride = slab_stride;
+      ha->L = L;
+      ha->nft = lzf.n;
+      ha->nct = lzc.n;
+      ha->S = S_;
+      AI_HIP(hipMemcpyAsync(ctx->lz_args_dev, ha, sizeof(LzArgs), hipMemcpyHostToDevice, st));
+      AI_HIP(hipMemsetAsync(ctx->lz_step_dev, 0, 2 * sizeof(int32_t), st));
+      int launched = 0;
+      while (launched < mcap && !done) {
+        const int upto = std::min(launched + AI_GRAPH_STEPS, mcap);
+        for (int j = launched; j <= upto; ++j) AI_TRY(ensure_vec(j));
+        AI_TRY(sync_slabtab());
+        AI_HIP(hipGraphLaunch(gexec, st));
+        launched += AI_GRAPH_STEPS;
+        const int m = std::min(launched, mcap);
+        if (nchecks < AI_MAX_CHECKS) {
+          if (pending.size() - phead >= (size_t)AI_CHECK_DEPTH - 1) AI_TRY(reap(true));
+          const int cd = (launched / AI_GRAPH_STEPS) % AI_CHECK_DEPTH;  // the slot k_lz_bnew_g wrote
+          const double* bn = bnew_buf.p + (size_t)cd * (S_ + 1);
+          AI_HIP(hipEventRecord(ctx->chk_ev1[cd], st));
+          AI_HIP(hipStreamWaitEvent(ctx->side, ctx->chk_ev1[cd], 0));
+          hipLaunchKernelGGL(k_lz_check, dim3(S_), dim3(64), (size_t)2 * m * sizeof(double), ctx->side, seg_start.p, segrange.p, s_mode.p, L, bn,
+                             m, opt.tol, opt.max_iter, m - last_check_m, rowptr, s_theta.p, s_resid.p, slots.p + nchecks, work.p);
+          AI_KERNEL_CHECK();
+          AI_HIP(hipMemcpyAsync(&ctx->pinned[nchecks % AI_PINNED_INTS], slots.p + nchecks, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->side));
+          AI_HIP(hipEventRecord(ctx->chk_ev[cd], ctx->side));
+          pending.push_back(Pending{nchecks, m, cd});
+          ++nchecks;
+          last_check_m = m;
+        }
+        // at most two batches past an unread check
+        const bool must = (phead < pending.size()) && (m - pending[phead].m >= 2 * AI_GRAPH_STEPS || m == mcap);
+        AI_TRY(reap(must));
+      }
+      steps = std::min(launched, mcap);
+    }
+    for (int j = 0; j < mcap && !done && !use_graph; ++j) {
       AI_TRY(ensure_vec(j + 1));
       if (time_spmv) {
         while (evpool.size() < (size_t)2 * (j + 1)) {
@@ -1822,7 +1985,7 @@ class Solver {
         AI_KERNEL_CHECK();
         AI_HIP(hipMemcpyAsync(&ctx->pinned[nchecks % AI_PINNED_INTS], slots.p + nchecks, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->side));
         AI_HIP(hipEventRecord(ctx->chk_ev[cd], ctx->side));
-        pending.push_back(Pending{nchecks, m});
+        pending.push_back(Pending{nchecks, m, cd});
         ++nchecks;
         last_check_m = m;
         if (m >= next_check) next_check = m + std::max(opt.check_every, (m / 8 / opt.check_every) * opt.check_every);
@@ -1927,10 +2090,45 @@ class Solver {
   size_t slabtab_n = 0;
   int sync_slabtab() {
     if (slabtab_n == slabs.size()) return AI_OK;
+    if (slabs.size() > 500) {
+      ai_set_error("internal: more than 500 Lanczos slabs");
+      return AI_ERR_INTERNAL;
+    }
     AI_TRY(d_slabtab.ensure(512));
-    AI_HIP(hipMemcpyAsync(d_slabtab.p, slabs.data(), slabs.size() * sizeof(double*), hipMemcpyHostToDevice, st));
-    AI_HIP(hipStreamSynchronize(st));
+    // the table only ever grows by appending, so rewriting the pinned copy while an earlier
+    // upload is still in flight is harmless; no synchronisation needed
+    double** pin = (double**)(ctx->stage + AI_STAGE_BYTES / 2 - 8192);
+    for (size_t i = 0; i < slabs.size(); ++i) pin[i] = slabs[i];
+    AI_HIP(hipMemcpyAsync(d_slabtab.p, pin, slabs.size() * sizeof(double*), hipMemcpyHostToDevice, st));
     slabtab_n = slabs.size();
+    return AI_OK;
+  }
+
+  // instantiated graph of AI_GRAPH_STEPS x (SpMV, update) + b_m, for a grid-size class
+  int lz_graph(int nft, int nct, hipGraphExec_t* out) {
+    int gf = 64;
+    while (gf < nft) gf <<= 1;
+    const int gc = gf / (AI_COARSE_ROWS / AI_FINE_ROWS) + 128;
+    if (nct > gc) return AI_ERR_INTERNAL;  // caller falls back to plain launches
+    for (auto& g : ctx->lz_graphs)
+      if (g.grid_f == gf && g.grid_c == gc) {
+        *out = g.exec;
+        return AI_OK;
+      }
+    const LzArgs* A = (const LzArgs*)ctx->lz_args_dev;
+    hipGraph_t graph;
+    AI_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    for (int u = 0; u < AI_GRAPH_STEPS; ++u) {
+      hipLaunchKernelGGL(k_lz_spmv_g, dim3(gf), dim3(AI_BLOCK), 0, st, A);
+      hipLaunchKernelGGL(k_lz_update_g, dim3(gc), dim3(AI_BLOCK), 0, st, A);
+    }
+    hipLaunchKernelGGL(k_lz_bnew_g, dim3(128), dim3(64), 0, st, A);
+    AI_HIP(hipStreamEndCapture(st, &graph));
+    hipGraphExec_t exec;
+    AI_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    AI_HIP(hipGraphDestroy(graph));
+    ctx->lz_graphs.push_back(ai_ctx::GraphEntry{gf, gc, exec});
+    *out = exec;
     return AI_OK;
   }
 
@@ -2141,24 +2339,35 @@ static void fill_opts(Solver& S, const ai_ncut_opts* opts) {
   S.time_spmv = (opts->reserved & 1) != 0;
 }
 
-extern "C" int ai_ncut(ai_ctx* ctx, const ai_csr* csr, int64_t num_points_orig, double T, double split_lim, const ai_ncut_opts* opts,
-                       int32_t* labels_out, int32_t* n_groups, ai_ncut_stats* stats_out) {
-  if (!ctx || !csr || !labels_out || !n_groups || num_points_orig < 0) {
-    ai_set_error("ai_ncut: bad argument");
-    return AI_ERR_BAD_ARG;
-  }
-  AI_HIP(hipSetDevice(ctx->device));
-  const double t0 = now_ms();
-  ArenaScope arena_scope(&ctx->arena);  // declared before the solver: its buffers die first
+// The recursion over one graph that holds `nchunks` independent chunks back to back (rows
+// off[c] .. off[c+1]); every chunk starts as its own root segment and keeps its own original
+// point count for the split_lim gate.  csr->orig holds chunk-LOCAL point ids.
+static int ncut_impl(ai_ctx* ctx, const ai_csr* csr, int nchunks, const int64_t* off, const int64_t* n_orig, double T, double split_lim,
+                     const ai_ncut_opts* opts, int32_t* const* labels_out, int32_t* n_groups, ai_ncut_stats* stats_out, double t0) {
   Solver S(ctx, csr);
   fill_opts(S, opts);
   const int n = (int)csr->n;
   AI_TRY(S.begin(false));
   std::vector<int32_t> leaf_starts;
-  if (eligible(n, num_points_orig, split_lim))
-    S.segs.push_back(SegHost{0, n, 0, 0, 1});
-  else
-    leaf_starts.push_back(0);
+  for (int c = 0; c < nchunks; ++c) {
+    const int nc = (int)(off[c + 1] - off[c]);
+    if (eligible(nc, n_orig[c], split_lim))
+      S.segs.push_back(SegHost{(int)off[c], nc, (int)off[c], 0, 1, c});
+    else
+      leaf_starts.push_back((int32_t)off[c]);
+  }
+  // compact order of the first level = rows of the eligible chunks, back to back
+  if ((int)S.segs.size() != nchunks) {
+    int pos = 0;
+    for (auto& sg : S.segs) {
+      if (sg.start != pos) {
+        ai_set_error("ai_ncut_batch: a chunk too small to be split (n <= 2 or below split_lim) must come after the others");
+        return AI_ERR_BAD_ARG;
+      }
+      pos += sg.n;
+    }
+    S.na = pos;
+  }
   hipStream_t st = ctx->stream;
   std::vector<int32_t> h_split, h_ntrue;
   std::vector<double> h_mcut;
@@ -2202,17 +2411,17 @@ extern "C" int ai_ncut(ai_ctx* ctx, const ai_csr* csr, int64_t num_points_orig, 
       }
       // a null-vector cut of cost exactly 0 runs between whole components: their labels stay valid
       const int carry = (sg.mode == 1 && h_mcut[s] == 0.0) ? 1 : 0;
-      if (eligible(na_, num_points_orig, 0.01)) {
+      if (eligible(na_, n_orig[sg.chunk], 0.01)) {
         cA[s] = cstart;
-        next.push_back(SegHost{cstart, na_, sg.gstart, 0, carry ? 0 : 1});
+        next.push_back(SegHost{cstart, na_, sg.gstart, 0, carry ? 0 : 1, sg.chunk});
         cstart += na_;
         any_carry |= (carry != 0);
       } else {
         leaf_starts.push_back(sg.gstart);
       }
-      if (eligible(nb_, num_points_orig, 0.01)) {
+      if (eligible(nb_, n_orig[sg.chunk], 0.01)) {
         cB[s] = cstart;
-        next.push_back(SegHost{cstart, nb_, sg.gstart + na_, 0, carry ? 0 : 1});
+        next.push_back(SegHost{cstart, nb_, sg.gstart + na_, 0, carry ? 0 : 1, sg.chunk});
         cstart += nb_;
         any_carry |= (carry != 0);
       } else {
@@ -2272,21 +2481,27 @@ extern "C" int ai_ncut(ai_ctx* ctx, const ai_csr* csr, int64_t num_points_orig, 
     S.stats.ms_rebuild += ms2;
   }
   std::sort(leaf_starts.begin(), leaf_starts.end());
-  int g = -1;
+  // groups of chunk c = the leaf ranges inside [off[c], off[c+1]), numbered from 0 in emission order
   size_t li = 0;
-  for (int p = 0; p < n; ++p) {
-    while (li < leaf_starts.size() && leaf_starts[li] == p) {
-      ++g;
-      ++li;
+  int64_t total_groups = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    int g = -1;
+    const int32_t nloc = (int32_t)(off[c + 1] - off[c]);
+    for (int64_t p = off[c]; p < off[c + 1]; ++p) {
+      while (li < leaf_starts.size() && leaf_starts[li] == p) {
+        ++g;
+        ++li;
+      }
+      if (g < 0 || order[p] < 0 || order[p] >= nloc) {
+        ai_set_error("internal: final ordering is not a permutation (chunk %d, position %lld)", c, (long long)p);
+        return AI_ERR_INTERNAL;
+      }
+      labels_out[c][order[p]] = g;
     }
-    if (g < 0 || order[p] < 0 || order[p] >= n) {
-      ai_set_error("internal: final ordering is not a permutation (position %d)", p);
-      return AI_ERR_INTERNAL;
-    }
-    labels_out[order[p]] = g;
+    n_groups[c] = g + 1;
+    total_groups += g + 1;
   }
-  *n_groups = g + 1;
-  S.stats.n_groups = g + 1;
+  S.stats.n_groups = total_groups;
   {
     unsigned long long hw[2] = {0, 0};
     AI_HIP(hipMemcpyAsync(hw, S.work.p, sizeof(hw), hipMemcpyDeviceToHost, st));
@@ -2297,6 +2512,82 @@ extern "C" int ai_ncut(ai_ctx* ctx, const ai_csr* csr, int64_t num_points_orig, 
   S.stats.ms_total = now_ms() - t0;
   if (stats_out) *stats_out = S.stats;
   return AI_OK;
+}
+
+extern "C" int ai_ncut(ai_ctx* ctx, const ai_csr* csr, int64_t num_points_orig, double T, double split_lim, const ai_ncut_opts* opts,
+                       int32_t* labels_out, int32_t* n_groups, ai_ncut_stats* stats_out) {
+  if (!ctx || !csr || !labels_out || !n_groups || num_points_orig < 0) {
+    ai_set_error("ai_ncut: bad argument");
+    return AI_ERR_BAD_ARG;
+  }
+  AI_HIP(hipSetDevice(ctx->device));
+  const double t0 = now_ms();
+  ArenaScope arena_scope(&ctx->arena);  // declared before the solver: its buffers die first
+  const int64_t off[2] = {0, csr->n};
+  int32_t* lab[1] = {labels_out};
+  return ncut_impl(ctx, csr, 1, off, &num_points_orig, T, split_lim, opts, lab, n_groups, stats_out, t0);
+}
+
+extern "C" int ai_ncut_batch(ai_ctx* ctx, const ai_csr* const* graphs, int32_t count, const int64_t* num_points_orig, double T,
+                             double split_lim, const ai_ncut_opts* opts, int32_t* const* labels_out, int32_t* n_groups,
+                             ai_ncut_stats* stats_out) {
+  if (!ctx || !graphs || count < 1 || !num_points_orig || !labels_out || !n_groups) {
+    ai_set_error("ai_ncut_batch: bad argument");
+    return AI_ERR_BAD_ARG;
+  }
+  int64_t N = 0, E = 0;
+  for (int c = 0; c < count; ++c) {
+    if (!graphs[c] || !labels_out[c] || num_points_orig[c] < 0) {
+      ai_set_error("ai_ncut_batch: null graph / label buffer at position %d", c);
+      return AI_ERR_BAD_ARG;
+    }
+    N += graphs[c]->n;
+    E += graphs[c]->nnz;
+  }
+  if (N >= ((int64_t)1 << 30) || E >= ((int64_t)1 << 31)) {
+    ai_set_error("ai_ncut_batch: %lld rows / %lld entries exceed the int32 index range of this build", (long long)N, (long long)E);
+    return AI_ERR_BAD_ARG;
+  }
+  AI_HIP(hipSetDevice(ctx->device));
+  const double t0 = now_ms();
+  ArenaScope arena_scope(&ctx->arena);
+  hipStream_t st = ctx->stream;
+  // one block-diagonal graph: the chunks back to back (column ids shifted by the chunk's first row)
+  DevBuf<int32_t> rp, cl, og;
+  DevBuf<double> vl;
+  AI_TRY(rp.alloc((size_t)N + 1));
+  AI_TRY(cl.alloc((size_t)E));
+  AI_TRY(vl.alloc((size_t)E));
+  AI_TRY(og.alloc((size_t)N));
+  std::vector<int64_t> off(count + 1, 0);
+  int64_t eoff = 0;
+  for (int c = 0; c < count; ++c) {
+    const ai_csr* g = graphs[c];
+    const int64_t n = g->n, e = g->nnz;
+    off[c + 1] = off[c] + n;
+    hipLaunchKernelGGL(k_offset_copy, dim3((unsigned)((n + 1 + AI_BLOCK - 1) / AI_BLOCK)), dim3(AI_BLOCK), 0, st, rp.p + off[c],
+                       (const int32_t*)g->rowptr, n + 1, (int32_t)eoff);
+    AI_KERNEL_CHECK();
+    if (e) {
+      hipLaunchKernelGGL(k_offset_copy, dim3((unsigned)((e + AI_BLOCK - 1) / AI_BLOCK)), dim3(AI_BLOCK), 0, st, cl.p + eoff, (const int32_t*)g->col,
+                         e, (int32_t)off[c]);
+      AI_KERNEL_CHECK();
+      AI_HIP(hipMemcpyAsync(vl.p + eoff, g->val, (size_t)e * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+    hipLaunchKernelGGL(k_offset_copy, dim3((unsigned)((n + AI_BLOCK - 1) / AI_BLOCK)), dim3(AI_BLOCK), 0, st, og.p + off[c],
+                       (const int32_t*)g->orig, n, 0);
+    AI_KERNEL_CHECK();
+    eoff += e;
+  }
+  ai_csr merged;
+  merged.n = N;
+  merged.nnz = E;
+  merged.rowptr = rp.p;
+  merged.col = cl.p;
+  merged.val = vl.p;
+  merged.orig = og.p;
+  merged.device = ctx->device;
+  return ncut_impl(ctx, &merged, count, off.data(), num_points_orig, T, split_lim, opts, labels_out, n_groups, stats_out, t0);
 }
 
 extern "C" int ai_fiedler(ai_ctx* ctx, const ai_csr* csr, const ai_ncut_opts* opts, double* lambda2, double* ev_out, int32_t* iters,

@@ -26,7 +26,7 @@ from . import _ffi
 from .config import CONFIG, PROXIMITY_THRESHOLD, SPLIT_LIM
 
 __all__ = ["Context", "DeviceGraph", "get_affinity_matrix", "build_affinity", "normalized_cut", "ncuts",
-           "ncuts_labels", "ncuts_chunk", "default_context", "last_stats"]
+           "ncuts_labels", "ncuts_labels_batch", "ncuts_chunk", "default_context", "last_stats"]
 
 
 class Context:
@@ -206,6 +206,34 @@ def ncuts_labels(graph: DeviceGraph, num_points_orig: int, T: float, split_lim: 
                                    C.byref(o), lab.ctypes.data, C.byref(ng), C.byref(stats)), "ai_ncut")
     _last_stats = stats.as_dict()
     return lab, int(ng.value), _last_stats
+
+
+def ncuts_labels_batch(graphs, num_points_orig=None, T=CONFIG["T"], split_lim=SPLIT_LIM, *, tol=None, max_iter=None,
+                       check_every=None):
+    """`ncuts_labels` for several independent chunks in ONE call (``ai_ncut_batch``).
+
+    The chunks share every kernel launch (they are the root segments of one frontier), which is
+    how a GPU is kept busy by a map's many chunks.  Returns ([labels_c], [n_groups_c], stats);
+    each chunk's result is what `ncuts_labels` gives for it alone.
+    """
+    global _last_stats
+    graphs = list(graphs)
+    if not graphs:
+        return [], [], None
+    ctx = graphs[0].ctx
+    k = len(graphs)
+    norig = [g.n for g in graphs] if num_points_orig is None else [int(x) for x in num_points_orig]
+    labs = [np.empty(g.n, dtype=np.int32) for g in graphs]
+    gh = (C.c_void_p * k)(*[g._h for g in graphs])
+    lp = (C.c_void_p * k)(*[a.ctypes.data for a in labs])
+    no = (C.c_int64 * k)(*norig)
+    ng = (C.c_int32 * k)()
+    stats = _ffi.NcutStats()
+    o = _opts(tol, max_iter, check_every)
+    _ffi.check(_ffi.load().ai_ncut_batch(ctx._h, gh, k, no, float(T), float(split_lim), C.byref(o), lp, ng, C.byref(stats)),
+               "ai_ncut_batch")
+    _last_stats = stats.as_dict()
+    return labs, [int(x) for x in ng], _last_stats
 
 
 def _groups_from_labels(lab, ng, labels):

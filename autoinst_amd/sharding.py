@@ -34,18 +34,19 @@ def lpt_assign(sizes, world_size: int):
     return [sorted(x) for x in out]
 
 
-def gather_labels(local: dict, device=None):
+def gather_labels(local: dict, device=None, force: bool = False):
     """Gather ``{chunk_index: int32 label array}`` from every rank to rank 0.
 
     Uses the default ``torch.distributed`` process group (``nccl`` = RCCL on the GPUs, ``gloo``
     on CPU).  Two steps: all-gather of (count, total length) so every rank knows the padded
-    size, then a gather of one padded int32 buffer per rank.  Returns the merged dict on rank 0
-    and ``None`` elsewhere.  Without an initialised group it is the identity.
+    size, then an all-gather of one padded int32 buffer per rank.  Returns the merged dict on rank 0
+    and ``None`` elsewhere.  Without an initialised group (or with one rank, unless ``force``) it is
+    the identity.
     """
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return dict(local)
     world, rank = dist.get_world_size(), dist.get_rank()
     if device is None:
@@ -62,8 +63,10 @@ def gather_labels(local: dict, device=None):
     mx = int(max(int(s.item()) for s in sizes))
     buf = torch.zeros(mx, dtype=torch.int32, device=device)
     buf[: payload.shape[0]] = torch.from_numpy(payload).to(device)
-    recv = [torch.zeros_like(buf) for _ in range(world)] if rank == 0 else None
-    dist.gather(buf, recv, dst=0)
+    # all-gather (the one collective every backend has) of a few hundred KB per rank; only rank 0
+    # keeps the result.  A rooted gather would save nothing measurable at this size.
+    recv = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(recv, buf)
     if rank != 0:
         return None
     merged = {}

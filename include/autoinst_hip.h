@@ -119,6 +119,18 @@ int ai_ncut(ai_ctx* ctx, const ai_csr* csr, int64_t num_points_orig, double T, d
             const ai_ncut_opts* opts, int32_t* labels_out, int32_t* n_groups, ai_ncut_stats* stats);
 
 /*
+ * The same recursion over `count` independent chunks at once (run_pipeline.py:160-179 loops over
+ * them one by one).  The chunks become the root segments of ONE frontier, so every kernel launch is
+ * shared by all of them: a single chunk's launches are latency-bound on small frontiers, a batch
+ * fills them.  Per chunk c: graphs[c], num_points_orig[c], labels_out[c] (graphs[c]->n ints, group
+ * ids from 0 in that chunk's own emission order), n_groups[c].  Results are those of `count`
+ * separate ai_ncut calls.  stats (may be NULL) describes the whole batch.
+ */
+int ai_ncut_batch(ai_ctx* ctx, const ai_csr* const* graphs, int32_t count, const int64_t* num_points_orig,
+                  double T, double split_lim, const ai_ncut_opts* opts, int32_t* const* labels_out,
+                  int32_t* n_groups, ai_ncut_stats* stats);
+
+/*
  * Building blocks exposed for parity tests (top-level call of the recursion only).
  * ai_fiedler: eigenpair of the 2nd-smallest eigenvalue of L_sym = D^-1/2 (D - W) D^-1/2,
  *   W = w + I (normalized_cut.py:38-53); ev_out (n, host, original order) has unit norm and

@@ -150,3 +150,25 @@ def test_cfg5_eigs_smallest_disconnected_is_the_null_space(api):
     assert np.all(evals == 0.0)
     assert np.abs(L @ V).max() <= 1e-13
     assert np.abs(V.T @ V - np.eye(k)).max() <= 1e-12
+
+
+def test_rccl_gather_path_single_rank():
+    """The nccl (= RCCL) code path of the label gather, as far as one GPU allows: a 1-rank group."""
+    import os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    code = (
+        "import os, sys, numpy as np, torch, torch.distributed as dist\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from autoinst_amd import sharding\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
+        "loc = {3: np.arange(1000, dtype=np.int32) % 7, 5: np.arange(10, dtype=np.int32)}\n"
+        "out = sharding.gather_labels(loc, device=torch.device('cuda', 0), force=True)\n"
+        "assert sorted(out) == [3, 5] and all(np.array_equal(out[k], loc[k]) for k in loc)\n"
+        "t = torch.tensor([1.5], dtype=torch.float64, device='cuda'); dist.all_reduce(t, op=dist.ReduceOp.MAX); dist.barrier()\n"
+        "dist.destroy_process_group(); print('RCCL_OK')\n"
+    )
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout + r.stderr

@@ -198,3 +198,18 @@ def test_run_to_run_reproducible(api):
     a = api.ncuts(ch["points"], ch["tarl"], alpha=1.0, theta=0.5, gamma=0.0, T=0.03)
     b = api.ncuts(ch["points"], ch["tarl"], alpha=1.0, theta=0.5, gamma=0.0, T=0.03)
     assert len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_batched_chunks_equal_separate_calls(api):
+    """ai_ncut_batch: several chunks as root segments of one frontier give each chunk's own result."""
+    from autoinst_amd import synth
+    chunks = [synth.synthetic_chunk(n, seed, tarl=True) for n, seed in ((9000, 1), (4000, 2), (15000, 3))]
+    graphs = [api.build_affinity(c["points"], c["tarl"], alpha=1.0, theta=0.5, gamma=0.0) for c in chunks]
+    single = [api.ncuts_labels(g, g.n, 0.03) for g in graphs]
+    labs, ngs, st = api.ncuts_labels_batch(graphs, None, 0.03)
+    assert st["unconverged"] == 0
+    for (l1, n1, _), l2, n2 in zip(single, labs, ngs):
+        assert n1 == n2 and np.array_equal(l1, l2)
+    # a chunk below the split limit of ITS OWN original size stays whole, the others are unaffected
+    labs2, ngs2, _ = api.ncuts_labels_batch(graphs, [g.n for g in graphs[:2]] + [10 ** 9], 0.03)
+    assert ngs2[2] == 1 and np.all(labs2[2] == 0) and np.array_equal(labs2[0], labs[0])
