@@ -209,7 +209,7 @@ def ncuts_labels(graph: DeviceGraph, num_points_orig: int, T: float, split_lim: 
 
 
 def ncuts_labels_batch(graphs, num_points_orig=None, T=CONFIG["T"], split_lim=SPLIT_LIM, *, tol=None, max_iter=None,
-                       check_every=None):
+                       check_every=None, time_spmv=False):
     """`ncuts_labels` for several independent chunks in ONE call (``ai_ncut_batch``).
 
     The chunks share every kernel launch (they are the root segments of one frontier), which is
@@ -229,7 +229,7 @@ def ncuts_labels_batch(graphs, num_points_orig=None, T=CONFIG["T"], split_lim=SP
     no = (C.c_int64 * k)(*norig)
     ng = (C.c_int32 * k)()
     stats = _ffi.NcutStats()
-    o = _opts(tol, max_iter, check_every)
+    o = _opts(tol, max_iter, check_every, time_spmv)
     _ffi.check(_ffi.load().ai_ncut_batch(ctx._h, gh, k, no, float(T), float(split_lim), C.byref(o), lp, ng, C.byref(stats)),
                "ai_ncut_batch")
     _last_stats = stats.as_dict()

@@ -4,18 +4,20 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path over one batch of chunks per GPU (`--in-flight`, default 4
-independent chunks, each on its own context / HIP streams): affinity build (TARL + spatial) from
-inputs already resident in HBM, recursive normalized cut, labels back on the host, and (N > 1)
-the gather of the label arrays to rank 0.  Several chunks are kept in flight because one chunk's
-kernels are latency-bound (small frontiers); the single-chunk latency is reported next to it.  Workload = BASELINE.json configs[1]: a 200 000-point
+One "step" = one pass of the hot path over one batch of chunks per GPU: `--in-flight` (2) host
+threads, each with its own context / HIP streams, each pushing `--batch` (4) independent chunks
+through ONE batched call (the chunks are the root segments of one frontier and share every kernel
+launch): affinity build (TARL + spatial) from inputs already resident in HBM, recursive normalized
+cut, labels back on the host, and (N > 1) the gather of the label arrays to rank 0.  One chunk
+alone is latency-bound (thousands of dependent launches on small frontiers); its latency is
+reported next to the throughput, and the per-chunk counters / roofline come from that single run.  Workload = BASELINE.json configs[1]: a 200 000-point
 chunk, alpha = 1, theta = 0.5 (96-d features), T = 0.03; synthetic surface chunk.
 Chunks are independent, so ranks process different chunks with no data-path collective
 ("weak" scaling: the same number of chunks per rank per step).
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the fused Lanczos SpMV,
 `k_lz_spmv`): algorithmic bytes of its launches / their summed duration, both from a profiled
-repeat of the same step with HIP events around every launch on the library's stream.
+repeat of one batched call with HIP start/stop events on every dispatch (library's stream).
 `cpu_baseline` is the oracle (NumPy / SciPy restatement, scipy eigsh shift-invert as the
 reference) timed on this host on a bounded sample.
 """
@@ -72,7 +74,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--in-flight", type=int, default=4, help="independent chunks processed concurrently per GPU")
+    ap.add_argument("--in-flight", type=int, default=2, help="host threads (contexts) per GPU")
+    ap.add_argument("--batch", type=int, default=4, help="chunks per batched call (root segments of one frontier)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -96,32 +99,36 @@ def main():
 
     from concurrent.futures import ThreadPoolExecutor
 
-    K = max(1, args.in_flight)
+    K = max(1, args.in_flight)   # host threads per rank, each with its own context (HIP streams + workspace)
+    B = max(1, args.batch)       # chunks per ai_ncut_batch call: root segments of one frontier
     dev = torch.device("cuda", local_rank)
-    # K chunks per rank per step, each on its own context (own HIP streams + workspace), all
-    # resident in HBM.  Different seeds = different chunks of the map.
     ctxs = [api.Context(local_rank) for _ in range(K)]
     data = []
-    for k in range(K):
-        ch = synth.synthetic_chunk(N_POINTS, seed=rank * K + k, tarl=True)
+    for i in range(K * B):       # different seeds = different chunks of the map, all resident in HBM
+        ch = synth.synthetic_chunk(N_POINTS, seed=rank * K * B + i, tarl=True)
         data.append((torch.from_numpy(ch["points"]).to(dev), torch.from_numpy(ch["tarl"]).to(dev)))
     torch.cuda.synchronize()
     pool = ThreadPoolExecutor(max_workers=K)
 
-    def one_chunk(k, profile=False):
-        pts_d, tarl_d = data[k]
-        g = api.build_affinity(pts_d, tarl_d, alpha=CFG["alpha"], theta=CFG["theta"], gamma=CFG["gamma"], ctx=ctxs[k])
+    def one_batch(k, profile=False, only_first=False):
+        mine = data[k * B:(k + 1) * B][: 1 if only_first else B]
+        graphs = [api.build_affinity(p, f, alpha=CFG["alpha"], theta=CFG["theta"], gamma=CFG["gamma"], ctx=ctxs[k]) for p, f in mine]
         try:
-            lab, ng, st = api.ncuts_labels(g, N_POINTS, CFG["T"], time_spmv=profile)
+            if len(graphs) == 1:
+                lab, ng, st = api.ncuts_labels(graphs[0], N_POINTS, CFG["T"], time_spmv=profile)
+                labs, ngs = [lab], [ng]
+            else:
+                labs, ngs, st = api.ncuts_labels_batch(graphs, None, CFG["T"], time_spmv=profile)
         finally:
-            nnz = g.nnz
-            g.free()
-        return lab, ng, st, nnz
+            nnz = graphs[0].nnz
+            for g in graphs:
+                g.free()
+        return labs, ngs, st, nnz
 
     def step():
-        # the library calls release the GIL, so the K chunks really are in flight together
-        res = list(pool.map(one_chunk, range(K)))
-        local = {rank * K + k: res[k][0] for k in range(K)}
+        # the library calls release the GIL, so the K batches really are in flight together
+        res = list(pool.map(one_batch, range(K)))
+        local = {(rank * K + k) * B + b: res[k][0][b] for k in range(K) for b in range(B)}
         merged = sharding.gather_labels(local, device=dev) if world > 1 else local
         return res, merged
 
@@ -144,24 +151,28 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     res, merged = last
-    lab, ng, st, nnz = res[0]
+    nnz = res[0][3]
+    stb = res[0][2]
 
-    # one chunk alone (latency), then a profiled repeat: HIP start/stop events on every SpMV dispatch
+    # one chunk alone (latency and per-chunk counters), then a profiled repeat of one batched call:
+    # HIP start/stop events on every SpMV dispatch
+    one_batch(0, only_first=True)
     t1 = time.perf_counter()
     for _ in range(3):
-        one_chunk(0)
+        labs1, ngs1, st, _ = one_batch(0, only_first=True)
     latency_ms = 1e3 * (time.perf_counter() - t1) / 3
-    _, _, stp, _ = one_chunk(0, profile=True)
+    ng = ngs1[0]
+    _, _, stp, _ = one_batch(0, profile=True)   # the batched call as timed above, SpMV dispatches bracketed
     barrier()
 
     if rank == 0:
-        assert merged is not None and len(merged) == world * K and all(v.shape[0] == N_POINTS for v in merged.values())
+        assert merged is not None and len(merged) == world * K * B and all(v.shape[0] == N_POINTS for v in merged.values())
         launches = int(stp["lanczos_steps"])
         b = spmv_bytes(int(stp["spmv_rows"]), int(stp["spmv_nnz"]), launches)
         ach = b / (stp["ms_spmv"] * 1e-3) / 1e9 if stp["ms_spmv"] > 0 else 0.0
         out = {
             "metric": "chunks/sec (200k-pt TARL+Spatial NCuts chunk: affinity build + recursive normalized cut)",
-            "value": world * K * args.steps / elapsed,
+            "value": world * K * B * args.steps / elapsed,
             "unit": "chunks/sec",
             "n_gpus": world,
             "steps": args.steps,
@@ -173,10 +184,11 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "configs[1]: single 200k-point surface chunk, TARL(96-d)+Spatial affinities, "
-                                   f"alpha=1 theta=0.5 T=0.03; {K} independent chunks in flight per GPU per step",
-                       "n_points": N_POINTS, "nnz": int(nnz), "chunks_per_step": world * K, "chunks_in_flight_per_gpu": K,
+                                   f"alpha=1 theta=0.5 T=0.03; per GPU per step {K} host threads x {B} chunks batched into one frontier",
+                       "n_points": N_POINTS, "nnz": int(nnz), "chunks_per_step": world * K * B, "threads_per_gpu": K, "chunks_per_batch": B,
                        "parallelism": f"chunk-dp{world}"},
             "single_chunk_latency_ms": latency_ms,
+            "batch_ncut_ms": stb["ms_total"],
             "eigensolve_ms": st["ms_eigen"],
             "ncut_ms": st["ms_total"],
             "sweep_ms": st["ms_sweep"],
