@@ -191,10 +191,25 @@ __device__ __forceinline__ double sqdist16(const double* __restrict__ a, const d
   }
   return ai_group16_sum(s);
 }
+// the same with this row's own features already in registers (K16 = dim / 16 values per lane)
+template <int K16>
+__device__ __forceinline__ double sqdist16_reg(const double (&fi)[K16 > 0 ? K16 : 1], const double* __restrict__ b, int t) {
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < K16; ++k) {
+    const double d = fi[k] - b[t + 16 * k];
+    s = fma(d, d, s);
+  }
+  return ai_group16_sum(s);
+}
 
 // One wave per row, four edges in flight (16 lanes each).  On entry val[] holds the spatial
 // distance d_ij; on exit the affinity.  Factors are multiplied in the reference's order
-// (tarl * spatial * dino, ncuts_utils.py:151-156).
+// (tarl * spatial * dino, ncuts_utils.py:151-156).  TK / DK = feature width / 16 when the row's own
+// features are kept in registers for the whole row (96-d TARL: 6, 384-d DINO: 24), 0 = generic
+// width read from memory per edge.  Lane t always owns dimensions t, t + 16, ... in both forms, so
+// the summation order (and therefore every bit of the result) is the same.
+template <int TK, int DK>
 __global__ __launch_bounds__(AI_BLOCK) void k_weights(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                       double* __restrict__ val, const int32_t* __restrict__ orig, int64_t n,
                                                       const double* __restrict__ tarl, int32_t tdim,
@@ -208,6 +223,15 @@ __global__ __launch_bounds__(AI_BLOCK) void k_weights(const int32_t* __restrict_
   const bool use_t = (theta != 0.0) && tarl != nullptr;
   const bool use_d = (gamma != 0.0) && dino != nullptr;
   const bool nti = use_t ? (notarl[row] != 0) : false;
+  double fti[TK > 0 ? TK : 1], fdi[DK > 0 ? DK : 1];
+  if (TK > 0 && use_t) {
+#pragma unroll
+    for (int k = 0; k < TK; ++k) fti[k] = tarl[oi * tdim + t + 16 * k];
+  }
+  if (DK > 0 && use_d) {
+#pragma unroll
+    for (int k = 0; k < DK; ++k) fdi[k] = dino[oi * ddim + t + 16 * k];
+  }
   const int32_t e0 = rowptr[row], e1 = rowptr[row + 1];
   for (int32_t eb = e0; eb < e1; eb += 4) {
     const int32_t e = eb + grp;
@@ -217,10 +241,10 @@ __global__ __launch_bounds__(AI_BLOCK) void k_weights(const int32_t* __restrict_
     double t2 = 0.0, g2 = 0.0;
     if (use_t) {
       const bool skip = nti || (notarl[j] != 0);
-      t2 = sqdist16(tarl + oi * tdim, tarl + oj * tdim, tdim, t);
+      t2 = (TK > 0) ? sqdist16_reg<TK>(fti, tarl + oj * tdim, t) : sqdist16(tarl + oi * tdim, tarl + oj * tdim, tdim, t);
       if (skip) t2 = 0.0;
     }
-    if (use_d) g2 = sqdist16(dino + oi * ddim, dino + oj * ddim, ddim, t);
+    if (use_d) g2 = (DK > 0) ? sqdist16_reg<DK>(fdi, dino + oj * ddim, t) : sqdist16(dino + oi * ddim, dino + oj * ddim, ddim, t);
     if (act && t == 0) {
       const double d = val[e];
       double w = 1.0;
@@ -409,9 +433,17 @@ extern "C" int ai_affinity_build(ai_ctx* ctx, const double* xyz, int64_t n, cons
   }
   {
     const unsigned gw = (unsigned)((n + (AI_BLOCK / 64) - 1) / (AI_BLOCK / 64));
-    hipLaunchKernelGGL(k_weights, dim3(gw), dim3(AI_BLOCK), 0, st, (const int32_t*)A->rowptr, (const int32_t*)A->col, A->val,
-                       (const int32_t*)A->orig, n, d_tarl, tarl_dim, (const uint8_t*)notarl.p, d_dino, dino_dim, alpha, theta,
-                       gamma);
+    const bool t96 = (d_tarl == nullptr) || tarl_dim == 96, d384 = (d_dino == nullptr) || dino_dim == 384;
+#define AI_LAUNCH_W(TK, DK)                                                                                                          \
+  hipLaunchKernelGGL((k_weights<TK, DK>), dim3(gw), dim3(AI_BLOCK), 0, st, (const int32_t*)A->rowptr, (const int32_t*)A->col, A->val, \
+                     (const int32_t*)A->orig, n, d_tarl, tarl_dim, (const uint8_t*)notarl.p, d_dino, dino_dim, alpha, theta, gamma)
+    if (t96 && d384)
+      AI_LAUNCH_W(6, 24);
+    else if (t96)
+      AI_LAUNCH_W(6, 0);
+    else
+      AI_LAUNCH_W(0, 0);
+#undef AI_LAUNCH_W
     AI_HIPF(hipGetLastError());
   }
   AI_HIPF(hipStreamSynchronize(st));

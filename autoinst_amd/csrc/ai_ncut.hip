@@ -375,6 +375,83 @@ __global__ __launch_bounds__(AI_BLOCK) void k_lz_spmv_t(const Task* __restrict__
   spmv_body<LPR, ILP>(ai_xcd_task(blockIdx.x, ntask), ftasks, factive, rowptr, col, wm, sinv2, Rj, Z, pA, sm);
 }
 
+// ---- SELL-64 copy of the scaled matrix for large frontiers: per 64-row fine task the entries are
+// stored column-major (entry k of row r at off + k * 64 + r, rows padded to the task's longest row),
+// so that ONE lane owns ONE row: every load of col / wm is a fully coalesced 256-B / 512-B wave
+// access, no lane idles on a short tail, no cross-lane reduction.  Lanes of a wave are
+// consecutive Morton-ordered points whose neighbour lists walk the same 27 cells in the same
+// order, so their k-th gathers hit neighbouring addresses.
+__global__ __launch_bounds__(64) void k_sell_len(const Task* __restrict__ ftasks, const int32_t* __restrict__ rowptr,
+                                                 int32_t* __restrict__ spad) {
+  const Task tk = ftasks[blockIdx.x];
+  const int row = tk.x + threadIdx.x;
+  int len = (row < tk.y) ? rowptr[row + 1] - rowptr[row] : 0;
+  for (int o = 32; o > 0; o >>= 1) len = max(len, __shfl_xor(len, o, 64));
+  if (threadIdx.x == 0) spad[blockIdx.x] = len * 64;
+}
+
+__global__ __launch_bounds__(64) void k_sell_fill(const Task* __restrict__ ftasks, const int32_t* __restrict__ rowptr,
+                                                  const int32_t* __restrict__ col, const double* __restrict__ wm,
+                                                  const int32_t* __restrict__ soff, int32_t* __restrict__ scol,
+                                                  double* __restrict__ swm) {
+  const Task tk = ftasks[blockIdx.x];
+  const int lane = threadIdx.x, row = tk.x + lane;
+  const bool ok = row < tk.y;
+  const int p0 = ok ? rowptr[row] : 0, p1 = ok ? rowptr[row + 1] : 0;
+  const int base = soff[blockIdx.x];
+  const int len = (soff[blockIdx.x + 1] - base) >> 6;
+  for (int k = 0; k < len; ++k) {
+    const int p = p0 + k;
+    const bool in = p < p1;
+    scol[base + k * 64 + lane] = in ? col[p] : -1;
+    swm[base + k * 64 + lane] = in ? wm[p] : 0.0;
+  }
+}
+
+// z = M R_j from the SELL copy: one wave per fine task, one lane per row, four entries in flight
+__global__ __launch_bounds__(AI_BLOCK) void k_lz_spmv_sell(const Task* __restrict__ ftasks, const int32_t* __restrict__ factive, int ntask,
+                                                           const int32_t* __restrict__ soff, const int32_t* __restrict__ scol,
+                                                           const double* __restrict__ swm, const double* __restrict__ sinv2,
+                                                           const double* __restrict__ Rj, double* __restrict__ Z,
+                                                           double* __restrict__ pA) {
+  const int nblk = (ntask + 3) >> 2;
+  const int t = ai_xcd_task(blockIdx.x, nblk) * 4 + (threadIdx.x >> 6);
+  if (t >= ntask) return;
+  const int act = factive[t];
+  const Task tk = ftasks[t];
+  if (!act) return;
+  const int lane = threadIdx.x & 63, row = tk.x + lane;
+  const bool ok = row < tk.y;
+  const int gi = tk.w >> 1;  // index of this task among ALL fine tasks (the SELL copy covers every row)
+  const int base = soff[gi];
+  const int len = (soff[gi + 1] - base) >> 6;
+  const double ri = ok ? Rj[row] : 0.0, s2 = ok ? sinv2[row] : 0.0;
+  double sum = 0.0;
+  const int32_t* cp = scol + base + lane;
+  const double* wp = swm + base + lane;
+  int k = 0;
+  for (; k + 4 <= len; k += 4) {
+    int c[4];
+    double w[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      c[u] = cp[(k + u) * 64];
+      w[u] = wp[(k + u) * 64];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (c[u] >= 0) sum = fma(w[u], Rj[c[u]], sum);
+  }
+  for (; k < len; ++k) {
+    const int c = cp[k * 64];
+    if (c >= 0) sum = fma(wp[k * 64], Rj[c], sum);
+  }
+  const double z = fma(s2, ri, sum);
+  if (ok) Z[row] = z;
+  const double tot = ai_wave_sum(ok ? ri * z : 0.0);
+  if (lane == 0) pA[t] = tot;
+}
+
 struct LzSeg {
   int32_t* frozen;      // [S]
   int32_t* m;           // [S] size of T at freeze
@@ -1528,6 +1605,11 @@ class Solver {
   DevBuf<double> s_vol, s_volA, s_volB, s_scale, s_thr, s_costs, s_cu;
   // Lanczos history + vectors
   DevBuf<double> alpha_hist, b_hist, g_hist, coef, bnew_buf;
+  // SELL-64 copy of (col, wm) for the SpMV on large frontiers
+  DevBuf<int32_t> spad, soff, sell_col;
+  DevBuf<double> sell_wm;
+  bool sell_ready = false;
+  int sell_min_tasks = -1;
   int mcap = 0;
   std::vector<double*> slabs, owned_slabs;
   size_t slab_stride = 0;
@@ -1650,8 +1732,14 @@ class Solver {
         t.y = std::min(lo + rows_per_task, segs[s].start + segs[s].n);
         t.z = s;
         t.w = first ? 1 : 0;
-        // Lanczos lists: bits 1.. carry the segment's step cap (its Krylov dimension / the step limit)
-        if (lanczos_only) t.w |= std::max(1, std::min(opt.max_iter, segs[s].n - 1)) << 1;
+        // Lanczos lists, bits 1..: coarse tasks carry the segment's step cap (its Krylov dimension / the
+        // step limit), fine tasks their index among ALL fine tasks (the SELL copy is laid out over those)
+        if (lanczos_only) {
+          if (rows_per_task == AI_FINE_ROWS)
+            t.w |= (fine.h_seg0[s] + (lo - segs[s].start) / AI_FINE_ROWS) << 1;
+          else
+            t.w |= std::max(1, std::min(opt.max_iter, segs[s].n - 1)) << 1;
+        }
         first = false;
         tl.h.push_back(t);
       }
@@ -1701,6 +1789,23 @@ class Solver {
     hipLaunchKernelGGL(k_scale, dim3(fine.n), dim3(AI_BLOCK), 0, st, fine.d.p, rowptr, col, wraw, deg.p, sinv.p, s_vol.p, wm.p, sinv2.p, u1.p);
     AI_KERNEL_CHECK();
     std::vector<int32_t> ncomp(S_, 1);
+    // padded SELL sizes of every fine task; the total comes back with the component counts
+    if (sell_min_tasks < 0) {
+      const char* v = getenv("AI_SPMV_SELL_MIN");
+      sell_min_tasks = v ? atoi(v) : 1 << 30;
+    }
+    sell_ready = false;
+    const bool want_sell = fine.n >= sell_min_tasks;
+    int32_t* sell_total_pin = (int32_t*)(ctx->stage + AI_STAGE_BYTES / 2 + (AI_STAGE_BYTES / 8));
+    if (want_sell) {
+      AI_TRY(spad.ensure((size_t)fine.n + 1));
+      AI_TRY(soff.ensure((size_t)fine.n + 1));
+      hipLaunchKernelGGL(k_sell_len, dim3(fine.n), dim3(64), 0, st, (const Task*)fine.d.p, rowptr, spad.p);
+      AI_KERNEL_CHECK();
+      AI_TRY(ai_exclusive_scan_i32(st, spad.p, soff.p, fine.n, scantmp.p));
+      AI_HIP(hipMemcpyAsync(sell_total_pin, soff.p + fine.n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      if (!want_cc) AI_HIP(hipStreamSynchronize(st));
+    }
     if (want_cc) {
       bool any = false;
       for (auto& s : segs) any |= (s.need_cc != 0);
@@ -1747,6 +1852,17 @@ class Solver {
     pk.add(&factive.p, ones.data(), (size_t)lzf.n);
     pk.add(&cactive.p, ones.data(), (size_t)lzc.n);
     AI_TRY(pk.flush(blobB, st));
+    if (want_sell && lzf.n >= sell_min_tasks) {
+      const int32_t total = *sell_total_pin;  // arrived with the synchronisation above
+      if (total > 0 && (int64_t)total <= 4 * (int64_t)A->nnz + 64 * (int64_t)fine.n) {
+        AI_TRY(sell_col.ensure((size_t)total));
+        AI_TRY(sell_wm.ensure((size_t)total));
+        hipLaunchKernelGGL(k_sell_fill, dim3(fine.n), dim3(64), 0, st, (const Task*)fine.d.p, rowptr, col, (const double*)wm.p,
+                           (const int32_t*)soff.p, sell_col.p, sell_wm.p);
+        AI_KERNEL_CHECK();
+        sell_ready = true;
+      }
+    }
     return AI_OK;
   }
 
@@ -1812,6 +1928,20 @@ class Solver {
     return AI_OK;
   }
   int launch_spmv(int j, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+    if (sell_ready) {
+      const unsigned nb = (unsigned)((lzf.n + 3) / 4);
+      if (e0) {
+        hipExtLaunchKernelGGL(k_lz_spmv_sell, dim3(nb), dim3(AI_BLOCK), 0, st, e0, e1, 0, (const Task*)lzf.d.p, (const int32_t*)factive.p, lzf.n,
+                              (const int32_t*)soff.p, (const int32_t*)sell_col.p, (const double*)sell_wm.p, (const double*)sinv2.p,
+                              (const double*)vec(j), Y.p, pA.p);
+      } else {
+        hipLaunchKernelGGL(k_lz_spmv_sell, dim3(nb), dim3(AI_BLOCK), 0, st, (const Task*)lzf.d.p, (const int32_t*)factive.p, lzf.n,
+                           (const int32_t*)soff.p, (const int32_t*)sell_col.p, (const double*)sell_wm.p, (const double*)sinv2.p,
+                           (const double*)vec(j), Y.p, pA.p);
+      }
+      AI_KERNEL_CHECK();
+      return AI_OK;
+    }
     if (spmv_variant < 0) {
       const char* v = getenv("AI_SPMV_VARIANT");
       spmv_variant = v ? atoi(v) : 0;
