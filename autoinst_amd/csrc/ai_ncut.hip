@@ -307,7 +307,7 @@ __global__ __launch_bounds__(AI_BLOCK) void k_lz_init(const Task* __restrict__ c
 // 16 lanes per row (neighbour counts ~30-40) read 64-B / 128-B runs of col / wm; each lane group
 // keeps AI_ROW_ILP rows in flight so that the dependent chain rowptr -> col -> gather is overlapped
 // four deep; gathers of R_j are served by L2 / MALL.
-template <int LPR, int ILP>
+template <int LPR, int ILP, bool NOGATHER = false>
 __device__ __forceinline__ void spmv_body(int t, const Task* __restrict__ ftasks, const int32_t* __restrict__ factive,
                                           const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                           const double* __restrict__ wm, const double* __restrict__ sinv2,
@@ -346,7 +346,7 @@ __device__ __forceinline__ void spmv_body(int t, const Task* __restrict__ ftasks
     }
 #pragma unroll
     for (int u = 0; u < ILP; ++u)
-      if (c[u] >= 0) sum[u] = fma(w[u], Rj[c[u]], sum[u]);
+      if (c[u] >= 0) sum[u] = fma(w[u], NOGATHER ? (double)c[u] : Rj[c[u]], sum[u]);
   }
   double acc = 0.0;
 #pragma unroll
@@ -365,14 +365,14 @@ __device__ __forceinline__ void spmv_body(int t, const Task* __restrict__ ftasks
   if (threadIdx.x == 0) pA[t] = tot;
 }
 
-template <int LPR, int ILP>
+template <int LPR, int ILP, bool NOGATHER = false>
 __global__ __launch_bounds__(AI_BLOCK) void k_lz_spmv_t(const Task* __restrict__ ftasks, const int32_t* __restrict__ factive, int ntask,
                                                       const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                       const double* __restrict__ wm, const double* __restrict__ sinv2,
                                                       const double* __restrict__ Rj, double* __restrict__ Z,
                                                       double* __restrict__ pA) {
   __shared__ double sm[AI_BLOCK / 64];
-  spmv_body<LPR, ILP>(ai_xcd_task(blockIdx.x, ntask), ftasks, factive, rowptr, col, wm, sinv2, Rj, Z, pA, sm);
+  spmv_body<LPR, ILP, NOGATHER>(ai_xcd_task(blockIdx.x, ntask), ftasks, factive, rowptr, col, wm, sinv2, Rj, Z, pA, sm);
 }
 
 // ---- SELL-64 copy of the scaled matrix for large frontiers: per 64-row fine task the entries are
@@ -450,6 +450,23 @@ __global__ __launch_bounds__(AI_BLOCK) void k_lz_spmv_sell(const Task* __restric
   if (ok) Z[row] = z;
   const double tot = ai_wave_sum(ok ? ri * z : 0.0);
   if (lane == 0) pA[t] = tot;
+}
+
+// experiment: TPB consecutive fine tasks per block, back to back (neighbouring rows share most of
+// their gathered entries, so the block's L1 lines are re-used)
+template <int TPB>
+__global__ __launch_bounds__(AI_BLOCK) void k_lz_spmv_multi(const Task* __restrict__ ftasks, const int32_t* __restrict__ factive, int ntask,
+                                                            const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                            const double* __restrict__ wm, const double* __restrict__ sinv2,
+                                                            const double* __restrict__ Rj, double* __restrict__ Z,
+                                                            double* __restrict__ pA) {
+  __shared__ double sm[AI_BLOCK / 64];
+  const int nblk = (ntask + TPB - 1) / TPB;
+  const int b = ai_xcd_task(blockIdx.x, nblk);
+  for (int q = 0; q < TPB; ++q) {
+    const int t = b * TPB + q;
+    if (t < ntask) spmv_body<16, 4>(t, ftasks, factive, rowptr, col, wm, sinv2, Rj, Z, pA, sm);
+  }
 }
 
 struct LzSeg {
@@ -1914,14 +1931,14 @@ class Solver {
 
   // e0 / e1 (optional): HIP events that receive this dispatch's own start / stop timestamps
   int spmv_variant = -1;
-  template <int LPR, int ILP>
+  template <int LPR, int ILP, bool NOGATHER = false>
   int launch_spmv_t(int j, hipEvent_t e0, hipEvent_t e1) {
     static_assert((AI_BLOCK / LPR) * ILP == AI_FINE_ROWS, "a block covers exactly one fine task");
     if (e0) {
-      hipExtLaunchKernelGGL((k_lz_spmv_t<LPR, ILP>), dim3(lzf.n), dim3(AI_BLOCK), 0, st, e0, e1, 0, (const Task*)lzf.d.p, (const int32_t*)factive.p,
+      hipExtLaunchKernelGGL((k_lz_spmv_t<LPR, ILP, NOGATHER>), dim3(lzf.n), dim3(AI_BLOCK), 0, st, e0, e1, 0, (const Task*)lzf.d.p, (const int32_t*)factive.p,
                             lzf.n, rowptr, col, (const double*)wm.p, (const double*)sinv2.p, (const double*)vec(j), Y.p, pA.p);
     } else {
-      hipLaunchKernelGGL((k_lz_spmv_t<LPR, ILP>), dim3(lzf.n), dim3(AI_BLOCK), 0, st, (const Task*)lzf.d.p, (const int32_t*)factive.p, lzf.n,
+      hipLaunchKernelGGL((k_lz_spmv_t<LPR, ILP, NOGATHER>), dim3(lzf.n), dim3(AI_BLOCK), 0, st, (const Task*)lzf.d.p, (const int32_t*)factive.p, lzf.n,
                          rowptr, col, (const double*)wm.p, (const double*)sinv2.p, (const double*)vec(j), Y.p, pA.p);
     }
     AI_KERNEL_CHECK();
@@ -1951,6 +1968,20 @@ class Solver {
       case 2: return launch_spmv_t<32, 8>(j, e0, e1);
       case 3: return launch_spmv_t<4, 1>(j, e0, e1);
       case 4: return launch_spmv_t<64, 16>(j, e0, e1);
+      case 9: return launch_spmv_t<16, 4, true>(j, e0, e1);  // timing only: no gather of R_j (wrong results)
+      case 6:
+      case 7: {
+        const int tpb = spmv_variant == 6 ? 4 : 2;
+        const unsigned nb = (unsigned)((lzf.n + tpb - 1) / tpb);
+        if (tpb == 4)
+          hipLaunchKernelGGL((k_lz_spmv_multi<4>), dim3(nb), dim3(AI_BLOCK), 0, st, (const Task*)lzf.d.p, (const int32_t*)factive.p, lzf.n, rowptr,
+                             col, (const double*)wm.p, (const double*)sinv2.p, (const double*)vec(j), Y.p, pA.p);
+        else
+          hipLaunchKernelGGL((k_lz_spmv_multi<2>), dim3(nb), dim3(AI_BLOCK), 0, st, (const Task*)lzf.d.p, (const int32_t*)factive.p, lzf.n, rowptr,
+                             col, (const double*)wm.p, (const double*)sinv2.p, (const double*)vec(j), Y.p, pA.p);
+        AI_KERNEL_CHECK();
+        return AI_OK;
+      }
       default: return launch_spmv_t<16, 4>(j, e0, e1);
     }
   }

@@ -104,8 +104,11 @@ def main():
     dev = torch.device("cuda", local_rank)
     ctxs = [api.Context(local_rank) for _ in range(K)]
     data = []
-    for i in range(K * B):       # different seeds = different chunks of the map, all resident in HBM
-        ch = synth.synthetic_chunk(N_POINTS, seed=rank * K * B + i, tarl=True)
+    # K*B different chunks (seeds 0..K*B-1), all resident in HBM.  Every rank works on the SAME set, so
+    # the per-GPU work is exactly fixed as N grows (weak scaling); one chunk costs 26-59 ms depending
+    # on its seed, and a real map's spread is what sharding.lpt_assign balances.
+    for i in range(K * B):
+        ch = synth.synthetic_chunk(N_POINTS, seed=i, tarl=True)
         data.append((torch.from_numpy(ch["points"]).to(dev), torch.from_numpy(ch["tarl"]).to(dev)))
     torch.cuda.synchronize()
     pool = ThreadPoolExecutor(max_workers=K)
