@@ -15,6 +15,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """The suites need libautoinst_hip.so; build it (hipcc cross-compiles without a GPU) if it is missing."""
+    lib = os.path.join(ROOT, "autoinst_amd", "libautoinst_hip.so")
+    if not os.path.exists(lib):
+        import __graft_entry__
+        __graft_entry__.build()
+    yield
+
+
 def golden_names():
     return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.startswith("g") and f.endswith(".npz"))
 
