@@ -2894,6 +2894,63 @@ extern "C" int ai_bench_spmv(ai_ctx* ctx, const ai_csr* csr, int32_t reps, doubl
   return AI_OK;
 }
 
+namespace {
+__global__ __launch_bounds__(AI_BLOCK) void k_comp_flag(const int32_t* __restrict__ parent, int32_t n, int32_t root, int32_t* __restrict__ flag) {
+  const int i = blockIdx.x * AI_BLOCK + threadIdx.x;
+  if (i < n) flag[i] = (parent[i] == root) ? 1 : 0;
+}
+__global__ __launch_bounds__(AI_BLOCK) void k_comp_map(const int32_t* __restrict__ flag, const int32_t* __restrict__ fscan, int32_t n,
+                                                       const int32_t* __restrict__ orig, int32_t* __restrict__ map,
+                                                       int32_t* __restrict__ orig_sub) {
+  const int i = blockIdx.x * AI_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const int32_t d = flag[i] ? fscan[i] : -1;
+  map[i] = d;
+  if (d >= 0) orig_sub[d] = orig[i];
+}
+
+// eigenpairs 2 .. k1+1 of ONE connected graph: k1 (lambda, unit vector) pairs, vectors scattered into
+// full-length rows of `vecs` (row stride n_full) at the positions csr->orig names
+int eigs_connected(ai_ctx* ctx, const ai_csr* csr, const ai_ncut_opts* opts, int k1, int64_t n_full, std::vector<double>& lambdas,
+                   std::vector<double>& vecs, int* steps_out, double* max_resid) {
+  Solver S(ctx, csr);
+  fill_opts(S, opts);
+  const int n = (int)csr->n;
+  AI_TRY(S.begin(true));
+  AI_TRY(S.build_tasks());
+  AI_TRY(S.prepare(false));
+  hipStream_t st = ctx->stream;
+  k1 = std::min(k1, n - 1);
+  lambdas.clear();
+  vecs.clear();
+  if (k1 <= 0) return AI_OK;
+  DevBuf<double> out;
+  AI_TRY(out.alloc((size_t)k1 * n));
+  std::vector<double> thetas, resids;
+  int steps = 0;
+  AI_TRY(S.lanczos_fro(k1, thetas, resids, out.p, (size_t)n, &steps));
+  const int got = (int)thetas.size();
+  std::vector<double> h_out((size_t)got * n);
+  std::vector<int32_t> h_orig(n);
+  AI_HIP(hipMemcpyAsync(h_out.data(), out.p, h_out.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  AI_HIP(hipMemcpyAsync(h_orig.data(), S.orig, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  AI_HIP(hipStreamSynchronize(st));
+  vecs.assign((size_t)got * n_full, 0.0);
+  for (int i = 0; i < got; ++i) {
+    lambdas.push_back(1.0 - thetas[i]);
+    if (max_resid) *max_resid = std::max(*max_resid, resids[i]);
+    const double* src = &h_out[(size_t)i * n];
+    double n2 = 0.0;
+    for (int r = 0; r < n; ++r) n2 += src[r] * src[r];
+    const double rn = 1.0 / sqrt(n2);
+    double* dst = &vecs[(size_t)i * n_full];
+    for (int r = 0; r < n; ++r) dst[h_orig[r]] = src[r] * rn;
+  }
+  if (steps_out) *steps_out = std::max(*steps_out, steps);
+  return AI_OK;
+}
+}  // namespace
+
 extern "C" int ai_eigs_smallest(ai_ctx* ctx, const ai_csr* csr, int32_t k, const ai_ncut_opts* opts, double* evals, double* evecs,
                                 int32_t* iters, double* max_resid) {
   if (!ctx || !csr || !evals || !evecs || k < 1 || k > RITZ_MAXK || k > csr->n) {
@@ -2921,14 +2978,15 @@ extern "C" int ai_eigs_smallest(ai_ctx* ctx, const ai_csr* csr, int32_t k, const
   for (int i = 0; i < n; ++i)
     if (h_parent[i] == i) roots.push_back(i);
   const int ncomp = (int)roots.size();
+  const int nzero = std::min(ncomp, (int)k);
   memset(evecs, 0, (size_t)k * n * sizeof(double));
   if (iters) *iters = 0;
   if (max_resid) *max_resid = 0.0;
-  if (ncomp >= k) {
-    // the k smallest eigenvalues are all 0: the first k components in row order span a valid answer
+  // zero pairs: the first min(k, components) components in row order (any k of them are a valid answer)
+  {
     std::vector<int32_t> rank(n, -1);
-    std::vector<double> vol(k, 0.0);
-    for (int c = 0; c < k; ++c) rank[roots[c]] = c;
+    std::vector<double> vol(nzero, 0.0);
+    for (int c = 0; c < nzero; ++c) rank[roots[c]] = c;
     for (int i = 0; i < n; ++i) {
       const int c = rank[h_parent[i]];
       if (c >= 0) vol[c] += h_deg[i];
@@ -2937,42 +2995,76 @@ extern "C" int ai_eigs_smallest(ai_ctx* ctx, const ai_csr* csr, int32_t k, const
       const int c = rank[h_parent[i]];
       if (c >= 0) evecs[(size_t)c * n + h_orig[i]] = sqrt(h_deg[i] / vol[c]);
     }
-    for (int c = 0; c < k; ++c) evals[c] = 0.0;
-    return AI_OK;
+    for (int c = 0; c < nzero; ++c) evals[c] = 0.0;
   }
-  if (ncomp != 1) {
-    ai_set_error("ai_eigs_smallest: the graph has %d connected components with 1 < components < k = %d; pass one component at a time "
-                 "(every component adds a zero eigenvalue; the rest of the spectrum is the union of the components' spectra)", ncomp, k);
-    return AI_ERR_BAD_ARG;
-  }
-  // connected: eigenvalue 0 with u1, then the k - 1 largest Ritz pairs of the deflated M
-  double vol = 0.0;
-  for (int i = 0; i < n; ++i) vol += h_deg[i];
-  for (int i = 0; i < n; ++i) evecs[h_orig[i]] = sqrt(h_deg[i] / vol);
-  evals[0] = 0.0;
-  if (k == 1) return AI_OK;
-  DevBuf<double> out;
-  AI_TRY(out.alloc((size_t)(k - 1) * n));
-  std::vector<double> thetas, resids;
+  const int need = k - nzero;  // non-zero eigenvalues still wanted
+  if (need == 0) return AI_OK;
+  // The non-zero spectrum is the union of the components' spectra: take the `need` smallest non-zero
+  // pairs of every component (each a connected graph of its own) and merge.
+  struct Cand {
+    double lambda;
+    int comp, idx;
+  };
+  std::vector<Cand> cands;
+  std::vector<std::vector<double>> cvecs(ncomp);
   int steps = 0;
-  AI_TRY(S.lanczos_fro(k - 1, thetas, resids, out.p, (size_t)n, &steps));
-  if ((int)thetas.size() < k - 1) {
-    ai_set_error("ai_eigs_smallest: only %zu of %d eigenpairs could be formed", thetas.size() + 1, k);
+  double mr = 0.0;
+  for (int c = 0; c < ncomp; ++c) {
+    ai_csr sub;
+    const ai_csr* use = csr;
+    DevBuf<int32_t> s_rowptr, s_col, s_orig, s_cnt;
+    DevBuf<double> s_val;
+    if (ncomp > 1) {
+      // sub-graph of component c (rows keep their order); sub.orig = the caller's ids of those rows
+      const unsigned gr = (unsigned)((n + AI_BLOCK - 1) / AI_BLOCK);
+      const unsigned ge = (unsigned)(((int64_t)n * AI_LPR + AI_BLOCK - 1) / AI_BLOCK);
+      hipLaunchKernelGGL(k_comp_flag, dim3(gr), dim3(AI_BLOCK), 0, st, (const int32_t*)S.parent, n, roots[c], S.flag.p);
+      AI_KERNEL_CHECK();
+      AI_TRY(ai_exclusive_scan_i32(st, S.flag.p, S.fscan.p, n, S.scantmp.p));
+      int32_t nc = 0;
+      AI_HIP(hipMemcpyAsync(&nc, S.fscan.p + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      AI_HIP(hipStreamSynchronize(st));
+      if (nc < 2) continue;  // a single point has no non-zero eigenvalue
+      AI_TRY(s_orig.alloc(nc));
+      AI_TRY(s_rowptr.alloc((size_t)nc + 1));
+      AI_TRY(s_cnt.alloc((size_t)nc + 1));
+      hipLaunchKernelGGL(k_comp_map, dim3(gr), dim3(AI_BLOCK), 0, st, (const int32_t*)S.flag.p, (const int32_t*)S.fscan.p, n, S.orig, S.map.p,
+                         s_orig.p);
+      AI_KERNEL_CHECK();
+      AI_HIP(hipMemsetAsync(s_cnt.p, 0, ((size_t)nc + 1) * sizeof(int32_t), st));
+      hipLaunchKernelGGL(k_rebuild_count, dim3(ge), dim3(AI_BLOCK), 0, st, S.rowptr, S.col, (const int32_t*)S.flag.p, (const int32_t*)S.map.p, n,
+                         s_cnt.p);
+      AI_KERNEL_CHECK();
+      AI_TRY(ai_exclusive_scan_i32(st, s_cnt.p, s_rowptr.p, nc, S.scantmp.p));
+      int32_t nnz_c = 0;
+      AI_HIP(hipMemcpyAsync(&nnz_c, s_rowptr.p + nc, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      AI_HIP(hipStreamSynchronize(st));
+      AI_TRY(s_col.alloc((size_t)std::max(nnz_c, 1)));
+      AI_TRY(s_val.alloc((size_t)std::max(nnz_c, 1)));
+      hipLaunchKernelGGL(k_rebuild_fill, dim3(ge), dim3(AI_BLOCK), 0, st, S.rowptr, S.col, S.wraw, (const int32_t*)S.flag.p,
+                         (const int32_t*)S.map.p, n, (const int32_t*)s_rowptr.p, s_col.p, s_val.p);
+      AI_KERNEL_CHECK();
+      sub.n = nc;
+      sub.nnz = nnz_c;
+      sub.rowptr = s_rowptr.p;
+      sub.col = s_col.p;
+      sub.val = s_val.p;
+      sub.orig = s_orig.p;
+      sub.device = ctx->device;
+      use = &sub;
+    }
+    std::vector<double> lam;
+    AI_TRY(eigs_connected(ctx, use, opts, need, n, lam, cvecs[c], &steps, &mr));
+    for (int i = 0; i < (int)lam.size(); ++i) cands.push_back(Cand{lam[i], c, i});
+  }
+  if ((int)cands.size() < need) {
+    ai_set_error("ai_eigs_smallest: only %zu of %d eigenpairs could be formed", cands.size() + (size_t)nzero, k);
     return AI_ERR_NO_CONVERGENCE;
   }
-  std::vector<double> h_out((size_t)(k - 1) * n);
-  AI_HIP(hipMemcpyAsync(h_out.data(), out.p, h_out.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-  AI_HIP(hipStreamSynchronize(st));
-  double mr = 0.0;
-  for (int i = 0; i < k - 1; ++i) {
-    evals[i + 1] = 1.0 - thetas[i];
-    mr = std::max(mr, resids[i]);
-    const double* src = &h_out[(size_t)i * n];
-    double* dst = evecs + (size_t)(i + 1) * n;
-    double n2 = 0.0;
-    for (int r = 0; r < n; ++r) n2 += src[r] * src[r];
-    const double rn = 1.0 / sqrt(n2);
-    for (int r = 0; r < n; ++r) dst[h_orig[r]] = src[r] * rn;
+  std::stable_sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.lambda < b.lambda; });
+  for (int i = 0; i < need; ++i) {
+    evals[nzero + i] = cands[i].lambda;
+    memcpy(evecs + (size_t)(nzero + i) * n, &cvecs[cands[i].comp][(size_t)cands[i].idx * n], (size_t)n * sizeof(double));
   }
   if (iters) *iters = steps;
   if (max_resid) *max_resid = mr;

@@ -152,9 +152,10 @@ int ai_lsym_apply(ai_ctx* ctx, const ai_csr* csr, const double* x, double* y);
  * evals[k] ascending; evecs[j * n + i] = component i (caller's original order) of unit vector j.
  * Every connected component contributes one zero eigenvalue with eigenvector D^1/2 1_C / sqrt(vol_C)
  * (formed explicitly).  With >= k components the answer is k such pairs (any k of them are a
- * valid answer, as with SciPy); a connected graph gets Lanczos with full re-orthogonalisation for
- * the other k - 1 pairs (stops when the innermost pair's Ritz residual <= opts->tol).
- * 1 < components < k is AI_ERR_BAD_ARG: pass one component at a time.
+ * valid answer, as with SciPy).  Otherwise the remaining pairs are the smallest non-zero ones of the
+ * union of the components' spectra: each component is solved on its own by Lanczos with full
+ * re-orthogonalisation (stops when the innermost wanted pair's Ritz residual <= opts->tol) and
+ * the results are merged.
  */
 int ai_eigs_smallest(ai_ctx* ctx, const ai_csr* csr, int32_t k, const ai_ncut_opts* opts, double* evals,
                      double* evecs, int32_t* iters, double* max_resid);

@@ -172,3 +172,22 @@ def test_rccl_gather_path_single_rank():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_cfg5_eigs_smallest_few_components_vs_scipy(api):
+    """1 < components < k: zero pairs + the union of the components' spectra, merged."""
+    import scipy.sparse.linalg as spla
+    A, _ = _largest_component(api, 30_000, 4)
+    _, comp = connected_components(A, directed=False)
+    big = np.argsort(-np.bincount(comp))[:3]
+    idx = np.flatnonzero(np.isin(comp, big))
+    sub = sp.csr_matrix(A[idx][:, idx])
+    n, k = sub.shape[0], 12
+    g = api.DeviceGraph.from_scipy(sub)
+    evals, V, steps, resid = api.eigs_smallest(g, k, tol=1e-9)
+    L, _ = ncuts_ref.laplacian_sym(sub)
+    ref = np.sort(spla.eigsh(L, k, sigma=-1e-2, which="LM")[0])
+    assert np.all(evals[:3] == 0.0) and np.all(np.diff(evals) >= -1e-12)
+    assert np.abs(evals - ref).max() <= 1e-8, np.abs(evals - ref).max()
+    assert np.linalg.norm(L @ V - V * evals[None, :], axis=0).max() <= 1e-7
+    assert np.abs(V.T @ V - np.eye(k)).max() <= 1e-8
