@@ -30,8 +30,8 @@
 
 #include "ai_common.h"
 
-#define AI_FINE_ROWS 64      // rows per block in the 16-lanes-per-row kernels (4 rows in flight per lane group)
-#define AI_COARSE_ROWS 1024  // rows per block in the thread-per-row kernels
+#define AI_FINE_ROWS 32      // rows per block in the 16-lanes-per-row kernels (2 rows in flight per lane group; 16 / 64 / 128 measured slower)
+#define AI_COARSE_ROWS 512   // rows per block in the thread-per-row kernels (256 / 1024 measured within 2 %)
 #define AI_ROW_ILP (AI_FINE_ROWS / (AI_BLOCK / AI_LPR))
 #define AI_SLAB_VECS 32      // Lanczos vectors per HBM slab
 #define AI_SWEEP_VALS 40     // per-task sweep partials: cut[10], assocA[10], assocB[10], cntA[10]
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(AI_BLOCK) void k_lz_spmv_multi(const Task* __restri
   const int b = ai_xcd_task(blockIdx.x, nblk);
   for (int q = 0; q < TPB; ++q) {
     const int t = b * TPB + q;
-    if (t < ntask) spmv_body<16, 4>(t, ftasks, factive, rowptr, col, wm, sinv2, Rj, Z, pA, sm);
+    if (t < ntask) spmv_body<16, AI_ROW_ILP>(t, ftasks, factive, rowptr, col, wm, sinv2, Rj, Z, pA, sm);
   }
 }
 
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(AI_BLOCK) void k_lz_spmv_g(const LzArgs* __restrict
   const int nft = A->nft;
   if (j >= A->L.mcap || (int)blockIdx.x >= nft) return;
   const double* Rj = A->slabs[j / AI_SLAB_VECS] + (size_t)(j % AI_SLAB_VECS) * A->stride;
-  spmv_body<16, 4>(ai_xcd_task(blockIdx.x, nft), A->ftasks, A->L.factive, A->rowptr, A->col, A->wm, A->sinv2, Rj, A->Z, A->pA, sm);
+  spmv_body<16, AI_ROW_ILP>(ai_xcd_task(blockIdx.x, nft), A->ftasks, A->L.factive, A->rowptr, A->col, A->wm, A->sinv2, Rj, A->Z, A->pA, sm);
 }
 
 __global__ __launch_bounds__(AI_BLOCK) void k_lz_update_g(const LzArgs* __restrict__ A) {
@@ -1812,7 +1812,7 @@ class Solver {
       sell_min_tasks = v ? atoi(v) : 1 << 30;
     }
     sell_ready = false;
-    const bool want_sell = fine.n >= sell_min_tasks;
+    const bool want_sell = (AI_FINE_ROWS == 64) && fine.n >= sell_min_tasks;  // the SELL copy is laid out in 64-row slices
     int32_t* sell_total_pin = (int32_t*)(ctx->stage + AI_STAGE_BYTES / 2 + (AI_STAGE_BYTES / 8));
     if (want_sell) {
       AI_TRY(spad.ensure((size_t)fine.n + 1));
@@ -1964,11 +1964,7 @@ class Solver {
       spmv_variant = v ? atoi(v) : 0;
     }
     switch (spmv_variant) {
-      case 1: return launch_spmv_t<8, 2>(j, e0, e1);
-      case 2: return launch_spmv_t<32, 8>(j, e0, e1);
-      case 3: return launch_spmv_t<4, 1>(j, e0, e1);
-      case 4: return launch_spmv_t<64, 16>(j, e0, e1);
-      case 9: return launch_spmv_t<16, 4, true>(j, e0, e1);  // timing only: no gather of R_j (wrong results)
+      case 9: return launch_spmv_t<16, AI_ROW_ILP, true>(j, e0, e1);  // timing only: no gather of R_j (wrong results)
       case 6:
       case 7: {
         const int tpb = spmv_variant == 6 ? 4 : 2;
@@ -1982,7 +1978,7 @@ class Solver {
         AI_KERNEL_CHECK();
         return AI_OK;
       }
-      default: return launch_spmv_t<16, 4>(j, e0, e1);
+      default: return launch_spmv_t<16, AI_ROW_ILP>(j, e0, e1);
     }
   }
 
