@@ -12,4 +12,7 @@ def __getattr__(name):
                 "Context", "DeviceGraph", "default_context", "last_stats", "fiedler", "sweep", "lsym_apply", "bench_spmv", "eigs_smallest"):
         from . import ncuts_api as _n
         return getattr(_n, name)
+    if name in ("Metrics", "score", "label_pairs", "merge_chunks_unite_instances2", "merge_associate", "unique_points"):
+        from . import labels_api as _l
+        return getattr(_l, name)
     raise AttributeError(name)

@@ -21,6 +21,7 @@ SYMBOLS = (
     "ai_csr_from_host", "ai_csr_dims", "ai_csr_export", "ai_csr_free", "ai_ncut", "ai_fiedler",
     "ai_sweep", "ai_lsym_apply", "ai_bench_spmv", "ai_eigs_smallest",
     "ai_radius_mean_pool", "ai_nn1_project", "ai_ncut_batch",
+    "ai_label_pairs", "ai_merge_associate", "ai_unique_points",
 )
 
 
@@ -81,6 +82,9 @@ def load():
     lib.ai_radius_mean_pool.argtypes = [vp, vp, i64, vp, i64, vp, i32, dbl, C.c_int, vp, vp]
     lib.ai_nn1_project.argtypes = [vp, vp, i64, vp, i64, C.c_int, vp, vp]
     lib.ai_ncut_batch.argtypes = [vp, P(vp), i32, P(i64), dbl, dbl, P(NcutOpts), P(vp), P(i32), P(NcutStats)]
+    lib.ai_label_pairs.argtypes = [vp, vp, vp, i64, C.c_int, i64, vp, vp, vp, P(i64)]
+    lib.ai_merge_associate.argtypes = [vp, vp, vp, i64, vp, vp, i64, vp, dbl, i32, i32, C.c_int, vp, vp, vp, vp, vp]
+    lib.ai_unique_points.argtypes = [vp, vp, i64, C.c_int, vp, P(i64)]
     for name in SYMBOLS:
         if name not in ("ai_version", "ai_last_error"):
             getattr(lib, name).restype = C.c_int

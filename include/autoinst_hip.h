@@ -178,6 +178,40 @@ int ai_nn1_project(ai_ctx* ctx, const double* to_xyz, int64_t nt, const double* 
                    int mem_kind, int32_t* nn_index, double* nn_dist);
 
 /*
+ * "Next" row 4: the per-point parts of the scorer and of the chunk merge.
+ *
+ * ai_label_pairs: the contingency table of two label arrays -- the distinct (a[i], b[i]) pairs in
+ *   ascending (a, b) order with their counts.  Replaces the per-label np.unique / np.where /
+ *   np.intersect1d / np.union1d passes of pipeline/metrics/metrics_class.py:302-309 (filter_labels),
+ *   :60-114 (get_tp_fp), :181-235 (average_precision) and the np.unique of pred + gt * 2^32 of
+ *   pipeline/metrics/modified_LSTQ.py:34-60.  a, b: host or device per mem_kind.  pair_a / pair_b /
+ *   pair_count: HOST arrays of capacity `cap`; *n_pairs is always the full number of distinct pairs
+ *   (call again with a larger cap when it exceeds cap).
+ *
+ * ai_merge_associate: the per-point work of one iteration of merge_chunks_unite_instances2
+ *   (pipeline/utils/point_cloud/point_cloud_utils.py:397-463).  Instances are dense ids (0 = street /
+ *   no instance, the reference's black colour) whose numeric order is the order of the reference's
+ *   np.unique(colors, axis=0).  The map is cropped to the cube center +- side_length / 2 (inclusive,
+ *   :405-417).  For id1 in [1, n_inst1), id2 in [1, n_inst2), row-major [id1 * n_inst2 + id2]:
+ *     inter      = #chunk points of id2 inside the bounding box of the cropped points of id1 (:446-456);
+ *     common     = #distinct scalar coordinate values the two instances share, so that the reference's
+ *                  union (:458, np.unique of the concatenated arrays, flattened) is
+ *                  n_scalars1[id1] + n_scalars2[id2] - common;
+ *   n_points1[id1] = #cropped map points of id1 (0: the instance is not in the crop).
+ *   Outputs are HOST arrays; the point / id arrays are host or device per mem_kind.
+ *
+ * ai_unique_points: PointCloud.remove_duplicated_points() (:489): indices (ascending) of the first point
+ *   of every distinct coordinate triple.  keep_index (capacity n) is host or device per mem_kind.
+ */
+int ai_label_pairs(ai_ctx* ctx, const int32_t* a, const int32_t* b, int64_t n, int mem_kind, int64_t cap,
+                   int32_t* pair_a, int32_t* pair_b, int64_t* pair_count, int64_t* n_pairs);
+int ai_merge_associate(ai_ctx* ctx, const double* map_xyz, const int32_t* map_inst, int64_t n_map,
+                       const double* chunk_xyz, const int32_t* chunk_inst, int64_t n_chunk, const double* center,
+                       double side_length, int32_t n_inst1, int32_t n_inst2, int mem_kind, int32_t* inter,
+                       int32_t* common, int32_t* n_scalars1, int32_t* n_scalars2, int32_t* n_points1);
+int ai_unique_points(ai_ctx* ctx, const double* xyz, int64_t n, int mem_kind, int32_t* keep_index, int64_t* n_keep);
+
+/*
  * Timing hook for bench.py: runs `reps` fused Lanczos SpMV steps on the whole graph as
  * one segment and returns the average kernel time (HIP events on the context's stream)
  * plus the algorithmic byte count of one launch.
