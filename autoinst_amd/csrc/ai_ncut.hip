@@ -375,85 +375,275 @@ __global__ __launch_bounds__(AI_BLOCK) void k_lz_spmv_t(const Task* __restrict__
   spmv_body<LPR, ILP, NOGATHER>(ai_xcd_task(blockIdx.x, ntask), ftasks, factive, rowptr, col, wm, sinv2, Rj, Z, pA, sm);
 }
 
-// ---- SELL-64 copy of the scaled matrix for large frontiers: per 64-row fine task the entries are
-// stored column-major (entry k of row r at off + k * 64 + r, rows padded to the task's longest row),
-// so that ONE lane owns ONE row: every load of col / wm is a fully coalesced 256-B / 512-B wave
-// access, no lane idles on a short tail, no cross-lane reduction.  Lanes of a wave are
-// consecutive Morton-ordered points whose neighbour lists walk the same 27 cells in the same
-// order, so their k-th gathers hit neighbouring addresses.
-__global__ __launch_bounds__(64) void k_sell_len(const Task* __restrict__ ftasks, const int32_t* __restrict__ rowptr,
-                                                 int32_t* __restrict__ spad) {
-  const Task tk = ftasks[blockIdx.x];
-  const int row = tk.x + threadIdx.x;
-  int len = (row < tk.y) ? rowptr[row + 1] - rowptr[row] : 0;
-  for (int o = 32; o > 0; o >>= 1) len = max(len, __shfl_xor(len, o, 64));
-  if (threadIdx.x == 0) spad[blockIdx.x] = len * 64;
-}
+// ---- staged gather (the default SpMV): the 8-byte gathers of R_j, not the streamed bytes, bound the
+// plain kernel.  The ~1200 entries of a 32-row task touch only ~150-300 DISTINCT
+// columns (consecutive Morton-ordered rows share their 27 neighbour cells), so once per level every
+// Lanczos task gets its sorted distinct-column list `ucol` and every entry a 16-bit index into it;
+// a step then gathers each distinct R_j value ONCE into LDS (coalesced runs) and the per-entry
+// gather becomes an LDS read.  Sums are formed in exactly the order of the plain kernel.
+#define AI_ENC_MAXNNZ 4096  // entries of a task the encoder sorts in LDS
+#define AI_ENC_XCAP 1024    // distinct columns of a task staged in LDS (8 KB)
+struct TaskEnc {
+  int32_t uoff, ucnt;  // slice of the ucol pool; ucnt < 0: not encoded, the task gathers from global memory
+};
 
-__global__ __launch_bounds__(64) void k_sell_fill(const Task* __restrict__ ftasks, const int32_t* __restrict__ rowptr,
-                                                  const int32_t* __restrict__ col, const double* __restrict__ wm,
-                                                  const int32_t* __restrict__ soff, int32_t* __restrict__ scol,
-                                                  double* __restrict__ swm) {
+__global__ __launch_bounds__(AI_BLOCK) void k_lz_encode(const Task* __restrict__ ftasks, const int32_t* __restrict__ rowptr,
+                                                        const int32_t* __restrict__ col, int32_t pool_cap,
+                                                        int32_t* __restrict__ pool_ctr, int32_t* __restrict__ ucol,
+                                                        uint16_t* __restrict__ lidx, TaskEnc* __restrict__ enc) {
+  __shared__ int32_t sk[AI_ENC_MAXNNZ];
+  __shared__ int32_t uq[AI_ENC_XCAP];
+  __shared__ int32_t wsum[AI_BLOCK / 64];
+  __shared__ int32_t s_off;
   const Task tk = ftasks[blockIdx.x];
-  const int lane = threadIdx.x, row = tk.x + lane;
-  const bool ok = row < tk.y;
-  const int p0 = ok ? rowptr[row] : 0, p1 = ok ? rowptr[row + 1] : 0;
-  const int base = soff[blockIdx.x];
-  const int len = (soff[blockIdx.x + 1] - base) >> 6;
-  for (int k = 0; k < len; ++k) {
-    const int p = p0 + k;
-    const bool in = p < p1;
-    scol[base + k * 64 + lane] = in ? col[p] : -1;
-    swm[base + k * 64 + lane] = in ? wm[p] : 0.0;
+  const int p0 = rowptr[tk.x], cnt = rowptr[tk.y] - p0;
+  if (cnt > AI_ENC_MAXNNZ || cnt <= 0) {
+    if (threadIdx.x == 0) enc[blockIdx.x] = TaskEnc{0, -1};
+    return;
   }
+  int n = 64;
+  while (n < cnt) n <<= 1;
+  for (int i = threadIdx.x; i < n; i += AI_BLOCK) sk[i] = (i < cnt) ? col[p0 + i] : 0x7fffffff;
+  __syncthreads();
+  // bitonic sort of n (a power of two) keys in LDS
+  for (int k = 2; k <= n; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < (n >> 1); i += AI_BLOCK) {
+        const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)), hi = lo | j;
+        const int32_t a = sk[lo], b = sk[hi];
+        const bool up = (lo & k) == 0;
+        if ((a > b) == up) {
+          sk[lo] = b;
+          sk[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  // distinct values: thread t owns the sorted positions [t * per, (t + 1) * per)
+  const int per = n / AI_BLOCK > 0 ? n / AI_BLOCK : 1;
+  int heads = 0;
+  for (int q = 0; q < per; ++q) {
+    const int i = threadIdx.x * per + q;
+    if (i < cnt && (i == 0 || sk[i] != sk[i - 1])) ++heads;
+  }
+  int incl = heads;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o, 64);
+    if ((threadIdx.x & 63) >= o) incl += v;
+  }
+  if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  int base = incl - heads, total = 0;
+#pragma unroll
+  for (int w = 0; w < AI_BLOCK / 64; ++w) {
+    if (w < (int)(threadIdx.x >> 6)) base += wsum[w];
+    total += wsum[w];
+  }
+  if (total > AI_ENC_XCAP) {
+    if (threadIdx.x == 0) enc[blockIdx.x] = TaskEnc{0, -1};
+    return;
+  }
+  for (int q = 0; q < per; ++q) {
+    const int i = threadIdx.x * per + q;
+    if (i < cnt && (i == 0 || sk[i] != sk[i - 1])) uq[base++] = sk[i];
+  }
+  if (threadIdx.x == 0) s_off = atomicAdd(pool_ctr, total);
+  __syncthreads();
+  const int off = s_off;
+  if (off + total > pool_cap) {  // pool exhausted (never with the default sizing): plain gather for this task
+    if (threadIdx.x == 0) enc[blockIdx.x] = TaskEnc{0, -1};
+    return;
+  }
+  for (int i = threadIdx.x; i < total; i += AI_BLOCK) ucol[off + i] = uq[i];
+  for (int e = threadIdx.x; e < cnt; e += AI_BLOCK) {
+    const int32_t c = col[p0 + e];
+    int lo = 0, hi = total - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (uq[mid] < c) lo = mid + 1; else hi = mid;
+    }
+    lidx[p0 + e] = (uint16_t)lo;
+  }
+  if (threadIdx.x == 0) enc[blockIdx.x] = TaskEnc{off, total};
 }
 
-// z = M R_j from the SELL copy: one wave per fine task, one lane per row, four entries in flight
-__global__ __launch_bounds__(AI_BLOCK) void k_lz_spmv_sell(const Task* __restrict__ ftasks, const int32_t* __restrict__ factive, int ntask,
-                                                           const int32_t* __restrict__ soff, const int32_t* __restrict__ scol,
-                                                           const double* __restrict__ swm, const double* __restrict__ sinv2,
-                                                           const double* __restrict__ Rj, double* __restrict__ Z,
-                                                           double* __restrict__ pA) {
-  const int nblk = (ntask + 3) >> 2;
-  const int t = ai_xcd_task(blockIdx.x, nblk) * 4 + (threadIdx.x >> 6);
-  if (t >= ntask) return;
+template <int LPR, int ILP>
+__global__ __launch_bounds__(AI_BLOCK) void k_lz_spmv_x(const Task* __restrict__ ftasks, const int32_t* __restrict__ factive, int ntask,
+                                                        const TaskEnc* __restrict__ enc, const int32_t* __restrict__ ucol,
+                                                        const uint16_t* __restrict__ lidx, const int32_t* __restrict__ rowptr,
+                                                        const int32_t* __restrict__ col, const double* __restrict__ wm,
+                                                        const double* __restrict__ sinv2, const double* __restrict__ Rj,
+                                                        double* __restrict__ Z, double* __restrict__ pA) {
+  __shared__ double sm[AI_BLOCK / 64];
+  __shared__ double xs[AI_ENC_XCAP];
+  const int t = ai_xcd_task(blockIdx.x, ntask);
   const int act = factive[t];
   const Task tk = ftasks[t];
+  const TaskEnc en = enc[t];
   if (!act) return;
-  const int lane = threadIdx.x & 63, row = tk.x + lane;
-  const bool ok = row < tk.y;
-  const int gi = tk.w >> 1;  // index of this task among ALL fine tasks (the SELL copy covers every row)
-  const int base = soff[gi];
-  const int len = (soff[gi + 1] - base) >> 6;
-  const double ri = ok ? Rj[row] : 0.0, s2 = ok ? sinv2[row] : 0.0;
-  double sum = 0.0;
-  const int32_t* cp = scol + base + lane;
-  const double* wp = swm + base + lane;
-  int k = 0;
-  for (; k + 4 <= len; k += 4) {
-    int c[4];
-    double w[4];
+  if (en.ucnt < 0) {
+    spmv_body<LPR, ILP>(t, ftasks, factive, rowptr, col, wm, sinv2, Rj, Z, pA, sm);
+    return;
+  }
+  for (int i = threadIdx.x; i < en.ucnt; i += AI_BLOCK) xs[i] = Rj[ucol[en.uoff + i]];
+  const int l = threadIdx.x & (LPR - 1), r = threadIdx.x / LPR;
+  constexpr int GROUPS = AI_BLOCK / LPR;
+  int p0[ILP], p1[ILP];
+  double sum[ILP], ri[ILP], s2[ILP];
+  int len = 0;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      c[u] = cp[(k + u) * 64];
-      w[u] = wp[(k + u) * 64];
+  for (int u = 0; u < ILP; ++u) {
+    const int row = tk.x + r + u * GROUPS;
+    const bool ok = row < tk.y;
+    p0[u] = ok ? rowptr[row] : 0;
+    p1[u] = ok ? rowptr[row + 1] : 0;
+    ri[u] = (ok && l == 0) ? Rj[row] : 0.0;
+    s2[u] = (ok && l == 0) ? sinv2[row] : 0.0;
+    sum[u] = 0.0;
+  }
+#pragma unroll
+  for (int u = 0; u < ILP; ++u) len = max(len, p1[u] - p0[u]);
+  // the streamed loads of the first round do not depend on xs: issue them before the barrier
+  int c0[ILP];
+  double w0[ILP];
+#pragma unroll
+  for (int u = 0; u < ILP; ++u) {
+    const int p = p0[u] + l;
+    const bool ok = p < p1[u];
+    c0[u] = ok ? (int)lidx[p] : -1;
+    w0[u] = ok ? wm[p] : 0.0;
+  }
+  __syncthreads();
+  for (int k = l; k < len; k += LPR) {
+    int c[ILP];
+    double w[ILP];
+#pragma unroll
+    for (int u = 0; u < ILP; ++u) {
+      c[u] = c0[u];
+      w[u] = w0[u];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (c[u] >= 0) sum = fma(w[u], Rj[c[u]], sum);
+    for (int u = 0; u < ILP; ++u) {  // next round's entries are in flight while this round is summed
+      const int p = p0[u] + k + LPR;
+      const bool ok = p < p1[u];
+      c0[u] = ok ? (int)lidx[p] : -1;
+      w0[u] = ok ? wm[p] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < ILP; ++u)
+      if (c[u] >= 0) sum[u] = fma(w[u], xs[c[u]], sum[u]);
   }
-  for (; k < len; ++k) {
-    const int c = cp[k * 64];
-    if (c >= 0) sum = fma(wp[k * 64], Rj[c], sum);
+  double acc = 0.0;
+#pragma unroll
+  for (int u = 0; u < ILP; ++u) {
+    double sg = sum[u];
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) sg += __shfl_xor(sg, o, LPR);
+    const int row = tk.x + r + u * GROUPS;
+    if (l == 0 && row < tk.y) {
+      const double z = fma(s2[u], ri[u], sg);
+      Z[row] = z;
+      acc = fma(ri[u], z, acc);
+    }
   }
-  const double z = fma(s2, ri, sum);
-  if (ok) Z[row] = z;
-  const double tot = ai_wave_sum(ok ? ri * z : 0.0);
-  if (lane == 0) pA[t] = tot;
+  const double tot = ai_block_sum(acc, sm);
+  if (threadIdx.x == 0) pA[t] = tot;
 }
+
+// Flat form of the staged kernel: the task's entries are read as ONE contiguous, aligned stream
+// (every lane busy, no rowptr -> entry dependency), the products go to LDS, and the rows are summed
+// from LDS (16 lanes per row).  Products are rounded before they are added, so the last bits differ
+// from the fma chain of the row-structured kernels; the order is fixed, results are reproducible.
+#define AI_FLAT_UNROLL 4
+template <int LPR, int ILP>
+__global__ __launch_bounds__(AI_BLOCK) void k_lz_spmv_f(const Task* __restrict__ ftasks, const int32_t* __restrict__ factive, int ntask,
+                                                        const TaskEnc* __restrict__ enc, const int32_t* __restrict__ ucol,
+                                                        const uint16_t* __restrict__ lidx, const int32_t* __restrict__ rowptr,
+                                                        const int32_t* __restrict__ col, const double* __restrict__ wm,
+                                                        const double* __restrict__ sinv2, const double* __restrict__ Rj,
+                                                        double* __restrict__ Z, double* __restrict__ pA) {
+  __shared__ double sm[AI_BLOCK / 64];
+  __shared__ double xs[AI_ENC_XCAP];
+  __shared__ double prod[AI_ENC_MAXNNZ];
+  const int t = ai_xcd_task(blockIdx.x, ntask);
+  const int act = factive[t];
+  const Task tk = ftasks[t];
+  const TaskEnc en = enc[t];
+  if (!act) return;
+  if (en.ucnt < 0) {
+    spmv_body<LPR, ILP>(t, ftasks, factive, rowptr, col, wm, sinv2, Rj, Z, pA, sm);
+    return;
+  }
+  const int P0 = rowptr[tk.x], cnt = rowptr[tk.y] - P0;
+  for (int i = threadIdx.x; i < en.ucnt; i += AI_BLOCK) xs[i] = Rj[ucol[en.uoff + i]];
+  const int l = threadIdx.x & (LPR - 1), r = threadIdx.x / LPR;
+  constexpr int GROUPS = AI_BLOCK / LPR;
+  int a0[ILP], a1[ILP];
+  double ri[ILP], s2[ILP];
+#pragma unroll
+  for (int u = 0; u < ILP; ++u) {
+    const int row = tk.x + r + u * GROUPS;
+    const bool ok = row < tk.y;
+    a0[u] = ok ? rowptr[row] - P0 : 0;
+    a1[u] = ok ? rowptr[row + 1] - P0 : 0;
+    ri[u] = (ok && l == 0) ? Rj[row] : 0.0;
+    s2[u] = (ok && l == 0) ? sinv2[row] : 0.0;
+  }
+  int c[AI_FLAT_UNROLL];
+  double w[AI_FLAT_UNROLL];
+#pragma unroll
+  for (int q = 0; q < AI_FLAT_UNROLL; ++q) {  // first round: independent of xs, in flight across the barrier
+    const int e = threadIdx.x + q * AI_BLOCK;
+    const bool ok = e < cnt;
+    c[q] = ok ? (int)lidx[P0 + e] : 0;
+    w[q] = ok ? wm[P0 + e] : 0.0;
+  }
+  __syncthreads();
+  for (int e0 = 0; e0 < cnt; e0 += AI_FLAT_UNROLL * AI_BLOCK) {
+    int cn[AI_FLAT_UNROLL];
+    double wn[AI_FLAT_UNROLL];
+#pragma unroll
+    for (int q = 0; q < AI_FLAT_UNROLL; ++q) {
+      const int e = e0 + AI_FLAT_UNROLL * AI_BLOCK + threadIdx.x + q * AI_BLOCK;
+      const bool ok = e < cnt;
+      cn[q] = ok ? (int)lidx[P0 + e] : 0;
+      wn[q] = ok ? wm[P0 + e] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < AI_FLAT_UNROLL; ++q) {
+      const int e = e0 + threadIdx.x + q * AI_BLOCK;
+      if (e < cnt) prod[e] = w[q] * xs[c[q]];
+    }
+#pragma unroll
+    for (int q = 0; q < AI_FLAT_UNROLL; ++q) {
+      c[q] = cn[q];
+      w[q] = wn[q];
+    }
+  }
+  __syncthreads();
+  double acc = 0.0;
+#pragma unroll
+  for (int u = 0; u < ILP; ++u) {
+    double sg = 0.0;
+    for (int k = a0[u] + l; k < a1[u]; k += LPR) sg += prod[k];
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) sg += __shfl_xor(sg, o, LPR);
+    const int row = tk.x + r + u * GROUPS;
+    if (l == 0 && row < tk.y) {
+      const double z = fma(s2[u], ri[u], sg);
+      Z[row] = z;
+      acc = fma(ri[u], z, acc);
+    }
+  }
+  const double tot = ai_block_sum(acc, sm);
+  if (threadIdx.x == 0) pA[t] = tot;
+}
+
 
 // experiment: TPB consecutive fine tasks per block, back to back (neighbouring rows share most of
 // their gathered entries, so the block's L1 lines are re-used)
+
 template <int TPB>
 __global__ __launch_bounds__(AI_BLOCK) void k_lz_spmv_multi(const Task* __restrict__ ftasks, const int32_t* __restrict__ factive, int ntask,
                                                             const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
@@ -665,15 +855,28 @@ __global__ __launch_bounds__(AI_BLOCK) void k_lz_update_g(const LzArgs* __restri
 // are < x, by sign changes of the leading principal minors p_i = det(T_i - x I), rescaled by
 // powers of two.  The LDS reads do not depend on the recurrence, so they pipeline.
 __device__ __forceinline__ int sturm_lt(const double* a, const double* bb, int m, double x) {
+  // one wave per SIMD: the recurrence is bound by instruction issue, so magnitudes are looked at every
+  // 8 rows only (|a - x| + b^2 < 4: eight rows move them by < 2^16; the rescale leaves 200 decades)
   double pm = 1.0, p = a[0] - x;
   int cnt = (p < 0.0) ? 1 : 0;
-#pragma unroll 4
-  for (int i = 1; i < m; ++i) {
-    double pn = (a[i] - x) * p - bb[i] * pm;
-    if (pn == 0.0) pn = (p > 0.0) ? -1e-300 : 1e-300;  // a zero takes the sign opposite to its predecessor
-    cnt += ((pn < 0.0) != (p < 0.0)) ? 1 : 0;
-    pm = p;
-    p = pn;
+  for (int i0 = 1; i0 < m; i0 += 8) {
+    double av[8], bv[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int i = min(i0 + t, m - 1);
+      av[t] = a[i];
+      bv[t] = bb[i];
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      if (i0 + t < m) {
+        double pn = (av[t] - x) * p - bv[t] * pm;
+        if (pn == 0.0) pn = (p > 0.0) ? -1e-300 : 1e-300;  // a zero takes the sign opposite to its predecessor
+        cnt += ((pn < 0.0) != (p < 0.0)) ? 1 : 0;
+        pm = p;
+        p = pn;
+      }
+    }
     const double ap = fabs(p);
     if (ap > 1e100 || ap < 1e-100) {
       const double sc = (ap > 1e100) ? 0x1p-400 : 0x1p400;
@@ -724,24 +927,30 @@ __global__ __launch_bounds__(64) void k_lz_bnew_g(const LzArgs* __restrict__ A) 
   if (threadIdx.x == 0) out[s] = sqrt(fmax(nn - gg * gg, 0.0));
 }
 
-// Convergence check after step j (m = j + 1 rows of T), one wave per running segment, on the side
-// stream: top eigenvalue of T_m by 64-way multisection; |s_m| by the recurrence from the bottom
-// row upwards (the growing, hence stable, direction); residual = b_m |s_m|.  Freezes the segment
-// when residual <= tol or T has reached the segment's dimension / the step cap.  slot[0] counts
-// the segments still running; work[] accumulates rows and stored entries the SpMV kernel
-// processed since the last check.  Reads only history entries [0, m), which later steps never touch.
-__global__ __launch_bounds__(64) void k_lz_check(const int32_t* __restrict__ seg_start, const TaskRange* __restrict__ seg_range,
-                                                 const int32_t* __restrict__ mode, LzSeg L, const double* __restrict__ bnew_in, int m,
-                                                 double tol, int max_iter, int steps_since, const int32_t* __restrict__ rowptr,
-                                                 double* __restrict__ theta_out, double* __restrict__ resid_out,
-                                                 int32_t* __restrict__ slot, unsigned long long* __restrict__ work) {
+// Convergence check after step j (m = j + 1 rows of T), one 256-thread block per running segment, on
+// the side stream: top eigenvalue of T_m by 256-way multisection (every thread one Sturm count, the
+// four waves on the CU's four SIMDs); |s_m| by the recurrence from the bottom row upwards (the growing,
+// hence stable, direction); residual = b_m |s_m|.  Freezes the segment when residual <= tol or T has
+// reached the segment's dimension / the step cap.  slot[0] counts the segments still running; work[]
+// accumulates rows and stored entries the SpMV kernel processed since the last check.  Reads only
+// history entries [0, m), which later steps never touch.
+#define AI_CHECK_THREADS 256
+__global__ __launch_bounds__(AI_CHECK_THREADS) void k_lz_check(const int32_t* __restrict__ seg_start, const TaskRange* __restrict__ seg_range,
+                                                               const int32_t* __restrict__ mode, LzSeg L, const double* __restrict__ bnew_in,
+                                                               int m, double tol, int max_iter, int steps_since,
+                                                               const int32_t* __restrict__ rowptr, double* __restrict__ theta_out,
+                                                               double* __restrict__ resid_out, int32_t* __restrict__ slot,
+                                                               unsigned long long* __restrict__ work, int with_rb) {
+  constexpr int NT = AI_CHECK_THREADS, NW = NT / 64;
+  __shared__ double smm[2][NW];
+  __shared__ int sfirst[2][NW];
   const int s = blockIdx.x;
   if (mode[s] != 0) return;
   if (L.frozen[s]) return;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int ns = seg_start[s + 1] - seg_start[s];
   const TaskRange rg = seg_range[s];
-  if (lane == 0) {
+  if (tid == 0) {
     atomicAdd(&work[0], (unsigned long long)ns * (unsigned long long)steps_since);
     atomicAdd(&work[1], (unsigned long long)(rowptr[seg_start[s + 1]] - rowptr[seg_start[s]]) * (unsigned long long)steps_since);
   }
@@ -751,49 +960,86 @@ __global__ __launch_bounds__(64) void k_lz_check(const int32_t* __restrict__ seg
   const int cap = min(min(ns - 1, max_iter), L.mcap);
   const bool last = (m >= cap) || !(bnew > 1e-14);
   m = min(m, cap);  // steps launched past the segment's cap did nothing (graph replay works in batches)
-  // T_m into LDS: a[0..m), b^2[0..m) (b^2[0] unused)
+  // T_m into LDS: a[0..m), b^2[0..m) (b^2[0] unused) and, when it fits, 1 / b[0..m)
   extern __shared__ double lds[];
   double* la = lds;
   double* lbb = lds + m;
-  for (int i = lane; i < m; i += 64) {
-    la[i] = ah[i];
-    const double bi = (i > 0) ? bh[i] : 0.0;
+  double* lrb = lds + 2 * m;
+  double lo = -1e300, hi = -1e300;  // lambda_max >= max diagonal, <= Gershgorin bound
+  for (int i = tid; i < m; i += NT) {
+    const double ai = ah[i];
+    const double bi = (i > 0) ? bh[i] : 0.0, br = (i + 1 < m) ? bh[i + 1] : 0.0;
+    la[i] = ai;
     lbb[i] = bi * bi;
-  }
-  __syncthreads();
-  // ---- top eigenvalue of T_m: lambda_max >= max diagonal, <= Gershgorin bound
-  double lo = -1e300, hi = -1e300;
-  for (int i = lane; i < m; i += 64) {
-    const double bl = (i > 0) ? bh[i] : 0.0, br = (i + 1 < m) ? bh[i + 1] : 0.0;
-    lo = fmax(lo, la[i]);
-    hi = fmax(hi, la[i] + fabs(bl) + fabs(br));
+    if (with_rb) lrb[i] = (i > 0) ? 1.0 / bi : 0.0;
+    lo = fmax(lo, ai);
+    hi = fmax(hi, ai + fabs(bi) + fabs(br));
   }
   for (int o = 32; o > 0; o >>= 1) {
     lo = fmax(lo, __shfl_xor(lo, o, 64));
     hi = fmax(hi, __shfl_xor(hi, o, 64));
   }
+  if (lane == 0) {
+    smm[0][wv] = lo;
+    smm[1][wv] = hi;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    lo = fmax(lo, smm[0][w]);
+    hi = fmax(hi, smm[1][w]);
+  }
   lo -= 1e-14 * fmax(fabs(lo), 1.0);
   hi += 1e-14 * fmax(fabs(hi), 1.0);
-  for (int round = 0; round < 12; ++round) {
-    const double w = (hi - lo) * (1.0 / 65.0);
-    const double x = lo + (lane + 1) * w;
-    const int c = sturm_lt(la, lbb, m, x);
-    const unsigned long long above = __ballot(c == m);  // lanes whose x exceeds every eigenvalue
-    if (above == 0ull) {
-      lo = lo + 64.0 * w;
-    } else {
-      const int l0 = __ffsll((long long)above) - 1;
-      hi = lo + (l0 + 1) * w;
-      lo = lo + l0 * w;
+  // index of the first thread of the block whose shift exceeds every eigenvalue (Sturm count m), or -1
+  int phase = 0;
+  auto first_above = [&](bool mine) -> int {
+    const unsigned long long above = __ballot(mine);
+    if (lane == 0) sfirst[phase][wv] = above ? wv * 64 + __ffsll((long long)above) - 1 : (1 << 30);
+    __syncthreads();
+    int j = 1 << 30;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) j = min(j, sfirst[phase][w]);
+    phase ^= 1;  // the next call writes the other row: one barrier per call is enough
+    return (j == (1 << 30)) ? -1 : j;
+  };
+  // Warm start from the previous check of this solve: T grew by rows and columns, so its top
+  // eigenvalue did not decrease (interlacing), and it normally lies within the previous residual of
+  // the previous value.  One round probes the ladder theta' + resid' * 2^j; the lowest rung above
+  // every eigenvalue closes the bracket, the rung below it opens it.
+  const double tprev = theta_out[s], rprev = resid_out[s];
+  if (tprev > 0.0 && rprev > 0.0) {
+    const double hi_g = hi, eps = 1e-15 * fmax(fabs(tprev), 1.0);
+    const double lo_w = fmax(lo, tprev - 1e-14 * fmax(fabs(tprev), 1.0));
+    const double x = fmin(hi_g, tprev + ldexp(rprev, tid) + eps);
+    const int j0 = first_above(sturm_lt(la, lbb, m, x) == m);
+    lo = lo_w;
+    if (j0 >= 0) {
+      hi = fmin(hi_g, tprev + ldexp(rprev, j0) + eps);
+      if (j0 > 0) lo = fmax(lo_w, fmin(hi_g, tprev + ldexp(rprev, j0 - 1) + eps));
     }
-    if (hi - lo <= 4.4e-16 * fmax(fabs(hi), 1e-300)) break;
   }
+  for (int round = 0; round < 12; ++round) {
+    if (hi - lo <= 4.4e-16 * fmax(fabs(hi), 1e-300)) break;  // block-uniform
+    const double w = (hi - lo) * (1.0 / (NT + 1));
+    const double x = lo + (tid + 1) * w;
+    const int j0 = first_above(sturm_lt(la, lbb, m, x) == m);
+    if (j0 < 0) {
+      lo = lo + (double)NT * w;
+    } else {
+      hi = lo + (j0 + 1) * w;
+      lo = lo + j0 * w;
+    }
+  }
+  if (wv != 0) return;
   const double theta = 0.5 * (lo + hi);
   // ---- |s_m| / ||s||: s_m = 1 at the start; `scale` follows the rescalings
   double sk1 = 0.0, sk = 1.0, sumsq = 1.0, scale = 1.0;  // s_{k+1}, s_k (every lane computes the same)
+#pragma unroll 8
   for (int k = m - 1; k >= 1; --k) {
     const double bu = (k + 1 < m) ? bh[k + 1] : 0.0;
-    const double sm1 = ((theta - la[k]) * sk - bu * sk1) / bh[k];
+    const double num = (theta - la[k]) * sk - bu * sk1;
+    const double sm1 = with_rb ? num * lrb[k] : num / bh[k];
     sk1 = sk;
     sk = sm1;
     sumsq += sk * sk;
@@ -1085,13 +1331,22 @@ __global__ __launch_bounds__(AI_BLOCK) void k_sweep(const Task* __restrict__ fta
                                                     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                     const double* __restrict__ wraw, const double* __restrict__ deg,
                                                     const uint8_t* __restrict__ bin, double* __restrict__ part) {
-  __shared__ double sm[AI_BLOCK / 64];
+  // the block's partial cut sums go through LDS transposed, so that each of the 10 columns is
+  // reduced by ONE wave (fixed order) instead of 40 block-wide reductions with two barriers each
+  __shared__ double scut[AI_NUM_CUTS][AI_BLOCK + 1];
+  __shared__ double sdeg[AI_FINE_ROWS];
+  __shared__ int sbin[AI_FINE_ROWS];
   const Task tk = ftasks[blockIdx.x];
   if (nosplit[tk.z]) return;
   const int l = threadIdx.x & (AI_LPR - 1), r = threadIdx.x / AI_LPR;
-  double cut[AI_NUM_CUTS], aa[AI_NUM_CUTS], ab[AI_NUM_CUTS], ca[AI_NUM_CUTS];
+  if (threadIdx.x < AI_FINE_ROWS) {
+    const int row = tk.x + threadIdx.x;
+    sbin[threadIdx.x] = (row < tk.y) ? (int)bin[row] : -1;
+    sdeg[threadIdx.x] = (row < tk.y) ? deg[row] : 0.0;
+  }
+  double cut[AI_NUM_CUTS];
 #pragma unroll
-  for (int k = 0; k < AI_NUM_CUTS; ++k) cut[k] = aa[k] = ab[k] = ca[k] = 0.0;
+  for (int k = 0; k < AI_NUM_CUTS; ++k) cut[k] = 0.0;
   for (int row = tk.x + r; row < tk.y; row += AI_BLOCK / AI_LPR) {
     const int bi = bin[row];
     const int p0 = rowptr[row], p1 = rowptr[row + 1];
@@ -1101,30 +1356,30 @@ __global__ __launch_bounds__(AI_BLOCK) void k_sweep(const Task* __restrict__ fta
 #pragma unroll
       for (int k = 0; k < AI_NUM_CUTS; ++k) cut[k] += (k >= bj && k < bi) ? w : 0.0;
     }
-    if (l == 0) {
-      const double d = deg[row];
-#pragma unroll
-      for (int k = 0; k < AI_NUM_CUTS; ++k) {
-        const bool inA = k < bi;
-        aa[k] += inA ? d : 0.0;
-        ab[k] += inA ? 0.0 : d;
-        ca[k] += inA ? 1.0 : 0.0;
-      }
-    }
   }
-  double* out = part + (size_t)blockIdx.x * AI_SWEEP_VALS;
 #pragma unroll
-  for (int k = 0; k < AI_NUM_CUTS; ++k) {
-    const double c = ai_block_sum(cut[k], sm);
-    const double a = ai_block_sum(aa[k], sm);
-    const double b = ai_block_sum(ab[k], sm);
-    const double n = ai_block_sum(ca[k], sm);
-    if (threadIdx.x == 0) {
-      out[k] = c;
-      out[AI_NUM_CUTS + k] = a;
-      out[2 * AI_NUM_CUTS + k] = b;
-      out[3 * AI_NUM_CUTS + k] = n;
+  for (int k = 0; k < AI_NUM_CUTS; ++k) scut[k][threadIdx.x] = cut[k];
+  __syncthreads();
+  double* out = part + (size_t)blockIdx.x * AI_SWEEP_VALS;
+  const int w = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  for (int k = w; k < AI_NUM_CUTS; k += AI_BLOCK / 64) {
+    double a = 0.0;
+#pragma unroll
+    for (int q = 0; q < AI_BLOCK / 64; ++q) a += scut[k][ln + 64 * q];
+    a = ai_wave_sum(a);
+    if (ln == 0) out[k] = a;
+  }
+  // assocA_k / assocB_k / |A_k| over the task's rows in row order (30 threads, 32 rows each)
+  if (threadIdx.x < 3 * AI_NUM_CUTS) {
+    const int which = threadIdx.x / AI_NUM_CUTS, k = threadIdx.x % AI_NUM_CUTS;
+    double a = 0.0;
+    for (int i = 0; i < AI_FINE_ROWS; ++i) {
+      const int bi = sbin[i];
+      if (bi < 0) break;
+      const bool inA = k < bi;
+      a += (which == 0) ? (inA ? sdeg[i] : 0.0) : (which == 1) ? (inA ? 0.0 : sdeg[i]) : (inA ? 1.0 : 0.0);
     }
+    out[(which + 1) * AI_NUM_CUTS + k] = a;
   }
 }
 
@@ -1622,11 +1877,13 @@ class Solver {
   DevBuf<double> s_vol, s_volA, s_volB, s_scale, s_thr, s_costs, s_cu;
   // Lanczos history + vectors
   DevBuf<double> alpha_hist, b_hist, g_hist, coef, bnew_buf;
-  // SELL-64 copy of (col, wm) for the SpMV on large frontiers
-  DevBuf<int32_t> spad, soff, sell_col;
-  DevBuf<double> sell_wm;
-  bool sell_ready = false;
-  int sell_min_tasks = -1;
+  // staged-gather encoding of the Lanczos tasks (k_lz_encode), rebuilt per level
+  DevBuf<uint16_t> lidx;
+  DevBuf<int32_t> ucol, enc_ctr;
+  DevBuf<TaskEnc> enc;
+  int32_t ucol_cap = 0;
+  bool enc_ready = false;
+  int enc_min_tasks = -1;  // AI_SPMV_STAGE_MIN: smallest Lanczos frontier (in tasks) that is encoded
   int mcap = 0;
   std::vector<double*> slabs, owned_slabs;
   size_t slab_stride = 0;
@@ -1678,6 +1935,10 @@ class Solver {
     AI_TRY(side.alloc(n));
     AI_TRY(bin.alloc(n));
     AI_TRY(slots.alloc(AI_MAX_CHECKS));
+    AI_TRY(lidx.alloc(e));
+    ucol_cap = (int32_t)std::min<size_t>(e / 2 + 4096, (size_t)1 << 30);
+    AI_TRY(ucol.alloc((size_t)ucol_cap));
+    AI_TRY(enc_ctr.alloc(1));
     AI_TRY(work.alloc(2));
     AI_HIP(hipMemsetAsync(work.p, 0, 2 * sizeof(unsigned long long), st));
     return AI_OK;
@@ -1750,7 +2011,7 @@ class Solver {
         t.z = s;
         t.w = first ? 1 : 0;
         // Lanczos lists, bits 1..: coarse tasks carry the segment's step cap (its Krylov dimension / the
-        // step limit), fine tasks their index among ALL fine tasks (the SELL copy is laid out over those)
+        // step limit), fine tasks their index among ALL fine tasks
         if (lanczos_only) {
           if (rows_per_task == AI_FINE_ROWS)
             t.w |= (fine.h_seg0[s] + (lo - segs[s].start) / AI_FINE_ROWS) << 1;
@@ -1806,23 +2067,6 @@ class Solver {
     hipLaunchKernelGGL(k_scale, dim3(fine.n), dim3(AI_BLOCK), 0, st, fine.d.p, rowptr, col, wraw, deg.p, sinv.p, s_vol.p, wm.p, sinv2.p, u1.p);
     AI_KERNEL_CHECK();
     std::vector<int32_t> ncomp(S_, 1);
-    // padded SELL sizes of every fine task; the total comes back with the component counts
-    if (sell_min_tasks < 0) {
-      const char* v = getenv("AI_SPMV_SELL_MIN");
-      sell_min_tasks = v ? atoi(v) : 1 << 30;
-    }
-    sell_ready = false;
-    const bool want_sell = (AI_FINE_ROWS == 64) && fine.n >= sell_min_tasks;  // the SELL copy is laid out in 64-row slices
-    int32_t* sell_total_pin = (int32_t*)(ctx->stage + AI_STAGE_BYTES / 2 + (AI_STAGE_BYTES / 8));
-    if (want_sell) {
-      AI_TRY(spad.ensure((size_t)fine.n + 1));
-      AI_TRY(soff.ensure((size_t)fine.n + 1));
-      hipLaunchKernelGGL(k_sell_len, dim3(fine.n), dim3(64), 0, st, (const Task*)fine.d.p, rowptr, spad.p);
-      AI_KERNEL_CHECK();
-      AI_TRY(ai_exclusive_scan_i32(st, spad.p, soff.p, fine.n, scantmp.p));
-      AI_HIP(hipMemcpyAsync(sell_total_pin, soff.p + fine.n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-      if (!want_cc) AI_HIP(hipStreamSynchronize(st));
-    }
     if (want_cc) {
       bool any = false;
       for (auto& s : segs) any |= (s.need_cc != 0);
@@ -1869,16 +2113,18 @@ class Solver {
     pk.add(&factive.p, ones.data(), (size_t)lzf.n);
     pk.add(&cactive.p, ones.data(), (size_t)lzc.n);
     AI_TRY(pk.flush(blobB, st));
-    if (want_sell && lzf.n >= sell_min_tasks) {
-      const int32_t total = *sell_total_pin;  // arrived with the synchronisation above
-      if (total > 0 && (int64_t)total <= 4 * (int64_t)A->nnz + 64 * (int64_t)fine.n) {
-        AI_TRY(sell_col.ensure((size_t)total));
-        AI_TRY(sell_wm.ensure((size_t)total));
-        hipLaunchKernelGGL(k_sell_fill, dim3(fine.n), dim3(64), 0, st, (const Task*)fine.d.p, rowptr, col, (const double*)wm.p,
-                           (const int32_t*)soff.p, sell_col.p, sell_wm.p);
-        AI_KERNEL_CHECK();
-        sell_ready = true;
-      }
+    if (enc_min_tasks < 0) {
+      const char* v = getenv("AI_SPMV_STAGE_MIN");
+      enc_min_tasks = v ? atoi(v) : 0;
+    }
+    enc_ready = false;
+    if (lzf.n > 0 && lzf.n >= enc_min_tasks) {
+      AI_TRY(enc.ensure((size_t)lzf.n));
+      AI_HIP(hipMemsetAsync(enc_ctr.p, 0, sizeof(int32_t), st));
+      hipLaunchKernelGGL(k_lz_encode, dim3(lzf.n), dim3(AI_BLOCK), 0, st, (const Task*)lzf.d.p, rowptr, col, ucol_cap, enc_ctr.p, ucol.p, lidx.p,
+                         enc.p);
+      AI_KERNEL_CHECK();
+      enc_ready = true;
     }
     return AI_OK;
   }
@@ -1945,20 +2191,6 @@ class Solver {
     return AI_OK;
   }
   int launch_spmv(int j, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
-    if (sell_ready) {
-      const unsigned nb = (unsigned)((lzf.n + 3) / 4);
-      if (e0) {
-        hipExtLaunchKernelGGL(k_lz_spmv_sell, dim3(nb), dim3(AI_BLOCK), 0, st, e0, e1, 0, (const Task*)lzf.d.p, (const int32_t*)factive.p, lzf.n,
-                              (const int32_t*)soff.p, (const int32_t*)sell_col.p, (const double*)sell_wm.p, (const double*)sinv2.p,
-                              (const double*)vec(j), Y.p, pA.p);
-      } else {
-        hipLaunchKernelGGL(k_lz_spmv_sell, dim3(nb), dim3(AI_BLOCK), 0, st, (const Task*)lzf.d.p, (const int32_t*)factive.p, lzf.n,
-                           (const int32_t*)soff.p, (const int32_t*)sell_col.p, (const double*)sell_wm.p, (const double*)sinv2.p,
-                           (const double*)vec(j), Y.p, pA.p);
-      }
-      AI_KERNEL_CHECK();
-      return AI_OK;
-    }
     if (spmv_variant < 0) {
       const char* v = getenv("AI_SPMV_VARIANT");
       spmv_variant = v ? atoi(v) : 0;
@@ -1978,8 +2210,28 @@ class Solver {
         AI_KERNEL_CHECK();
         return AI_OK;
       }
-      default: return launch_spmv_t<16, AI_ROW_ILP>(j, e0, e1);
+      case 1: return launch_spmv_t<16, AI_ROW_ILP>(j, e0, e1);  // plain gather from global memory
+      default: break;
     }
+    if (!enc_ready) return launch_spmv_t<16, AI_ROW_ILP>(j, e0, e1);
+    if (spmv_variant == 2) {
+      hipExtLaunchKernelGGL((k_lz_spmv_f<16, AI_ROW_ILP>), dim3(lzf.n), dim3(AI_BLOCK), 0, st, e0, e1, 0, (const Task*)lzf.d.p,
+                            (const int32_t*)factive.p, lzf.n, (const TaskEnc*)enc.p, (const int32_t*)ucol.p, (const uint16_t*)lidx.p, rowptr, col,
+                            (const double*)wm.p, (const double*)sinv2.p, (const double*)vec(j), Y.p, pA.p);
+      AI_KERNEL_CHECK();
+      return AI_OK;
+    }
+    if (e0) {
+      hipExtLaunchKernelGGL((k_lz_spmv_x<16, AI_ROW_ILP>), dim3(lzf.n), dim3(AI_BLOCK), 0, st, e0, e1, 0, (const Task*)lzf.d.p,
+                            (const int32_t*)factive.p, lzf.n, (const TaskEnc*)enc.p, (const int32_t*)ucol.p, (const uint16_t*)lidx.p, rowptr, col,
+                            (const double*)wm.p, (const double*)sinv2.p, (const double*)vec(j), Y.p, pA.p);
+    } else {
+      hipLaunchKernelGGL((k_lz_spmv_x<16, AI_ROW_ILP>), dim3(lzf.n), dim3(AI_BLOCK), 0, st, (const Task*)lzf.d.p, (const int32_t*)factive.p, lzf.n,
+                         (const TaskEnc*)enc.p, (const int32_t*)ucol.p, (const uint16_t*)lidx.p, rowptr, col, (const double*)wm.p,
+                         (const double*)sinv2.p, (const double*)vec(j), Y.p, pA.p);
+    }
+    AI_KERNEL_CHECK();
+    return AI_OK;
   }
 
   // Lock-step Lanczos over every mode-0 segment, then Ritz vectors into ev.
@@ -2025,7 +2277,7 @@ class Solver {
     // an event and read a few steps later, so the stream never drains.  A finished segment's
     // blocks exit at their activity flag, so steps launched past the end cost next to nothing;
     // the host still never runs more than AI_RUNAHEAD steps past an unread check.
-    const int AI_RUNAHEAD = 6;
+    static const int AI_RUNAHEAD = getenv("AI_RUNAHEAD") ? atoi(getenv("AI_RUNAHEAD")) : 6;
     struct Pending { int slot, m, ev; };
     std::vector<Pending> pending;  // FIFO of in-flight checks
     size_t phead = 0;
@@ -2093,8 +2345,10 @@ class Solver {
           const double* bn = bnew_buf.p + (size_t)cd * (S_ + 1);
           AI_HIP(hipEventRecord(ctx->chk_ev1[cd], st));
           AI_HIP(hipStreamWaitEvent(ctx->side, ctx->chk_ev1[cd], 0));
-          hipLaunchKernelGGL(k_lz_check, dim3(S_), dim3(64), (size_t)2 * m * sizeof(double), ctx->side, seg_start.p, segrange.p, s_mode.p, L, bn,
-                             m, opt.tol, opt.max_iter, m - last_check_m, rowptr, s_theta.p, s_resid.p, slots.p + nchecks, work.p);
+          const int with_rb = (size_t)3 * m * sizeof(double) <= (size_t)64 * 1024;
+          hipLaunchKernelGGL(k_lz_check, dim3(S_), dim3(AI_CHECK_THREADS), (size_t)(with_rb ? 3 : 2) * m * sizeof(double), ctx->side, seg_start.p, segrange.p,
+                             s_mode.p, L, bn, m, opt.tol, opt.max_iter, m - last_check_m, rowptr, s_theta.p, s_resid.p, slots.p + nchecks, work.p,
+                             with_rb);
           AI_KERNEL_CHECK();
           AI_HIP(hipMemcpyAsync(&ctx->pinned[nchecks % AI_PINNED_INTS], slots.p + nchecks, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->side));
           AI_HIP(hipEventRecord(ctx->chk_ev[cd], ctx->side));
@@ -2136,9 +2390,10 @@ class Solver {
         AI_KERNEL_CHECK();
         AI_HIP(hipEventRecord(ctx->chk_ev1[cd], st));
         AI_HIP(hipStreamWaitEvent(ctx->side, ctx->chk_ev1[cd], 0));
-        hipLaunchKernelGGL(k_lz_check, dim3(S_), dim3(64), (size_t)2 * m * sizeof(double), ctx->side, seg_start.p, segrange.p, s_mode.p, L,
-                           (const double*)bn, m, opt.tol, opt.max_iter, m - last_check_m, rowptr, s_theta.p, s_resid.p,
-                           slots.p + nchecks, work.p);
+        const int with_rb = (size_t)3 * m * sizeof(double) <= (size_t)64 * 1024;
+        hipLaunchKernelGGL(k_lz_check, dim3(S_), dim3(AI_CHECK_THREADS), (size_t)(with_rb ? 3 : 2) * m * sizeof(double), ctx->side, seg_start.p, segrange.p,
+                           s_mode.p, L, (const double*)bn, m, opt.tol, opt.max_iter, m - last_check_m, rowptr, s_theta.p, s_resid.p,
+                           slots.p + nchecks, work.p, with_rb);
         AI_KERNEL_CHECK();
         AI_HIP(hipMemcpyAsync(&ctx->pinned[nchecks % AI_PINNED_INTS], slots.p + nchecks, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->side));
         AI_HIP(hipEventRecord(ctx->chk_ev[cd], ctx->side));
