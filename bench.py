@@ -4,8 +4,8 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path over one batch of chunks per GPU: `--in-flight` (2) host
-threads, each with its own context / HIP streams, each pushing `--batch` (4) independent chunks
+One "step" = one pass of the hot path over one batch of chunks per GPU: `--in-flight` (4) host
+threads, each with its own context / HIP streams, each pushing `--batch` (6) independent chunks
 through ONE batched call (the chunks are the root segments of one frontier and share every kernel
 launch): affinity build (TARL + spatial) from inputs already resident in HBM, recursive normalized
 cut, labels back on the host, and (N > 1) the gather of the label arrays to rank 0.  One chunk
@@ -74,8 +74,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--in-flight", type=int, default=2, help="host threads (contexts) per GPU")
-    ap.add_argument("--batch", type=int, default=4, help="chunks per batched call (root segments of one frontier)")
+    ap.add_argument("--in-flight", type=int, default=4, help="host threads (contexts) per GPU")
+    ap.add_argument("--batch", type=int, default=6, help="chunks per batched call (root segments of one frontier)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
