@@ -203,7 +203,7 @@ __device__ __forceinline__ double sqdist16_reg(const double (&fi)[K16 > 0 ? K16 
   return ai_group16_sum(s);
 }
 
-// One wave per row, four edges in flight (16 lanes each).  On entry val[] holds the spatial
+// One wave per row, four edges in flight (16 lanes each) for the feature distances.  On entry val[] holds the spatial
 // distance d_ij; on exit the affinity.  Factors are multiplied in the reference's order
 // (tarl * spatial * dino, ncuts_utils.py:151-156).  TK / DK = feature width / 16 when the row's own
 // features are kept in registers for the whole row (96-d TARL: 6, 384-d DINO: 24), 0 = generic
@@ -215,7 +215,10 @@ __global__ __launch_bounds__(AI_BLOCK) void k_weights(const int32_t* __restrict_
                                                       const double* __restrict__ tarl, int32_t tdim,
                                                       const uint8_t* __restrict__ notarl, const double* __restrict__ dino,
                                                       int32_t ddim, double alpha, double theta, double gamma) {
-  const int64_t row = (int64_t)blockIdx.x * (AI_BLOCK / 64) + (threadIdx.x >> 6);
+  // workgroups are dealt round-robin to the 8 XCDs: remap so that each XCD walks one contiguous eighth of
+  // the Morton-ordered rows and the neighbours' feature rows are re-used from ITS 4 MB L2 (the 154 MB
+  // feature matrix itself only fits the Infinity Cache)
+  const int64_t row = (int64_t)ai_xcd_task(blockIdx.x, gridDim.x) * (AI_BLOCK / 64) + (threadIdx.x >> 6);
   if (row >= n) return;
   const int lane = threadIdx.x & 63;
   const int grp = lane >> 4, t = lane & 15;
@@ -233,24 +236,38 @@ __global__ __launch_bounds__(AI_BLOCK) void k_weights(const int32_t* __restrict_
     for (int k = 0; k < DK; ++k) fdi[k] = dino[oi * ddim + t + 16 * k];
   }
   const int32_t e0 = rowptr[row], e1 = rowptr[row + 1];
-  for (int32_t eb = e0; eb < e1; eb += 4) {
-    const int32_t e = eb + grp;
-    const bool act = e < e1;
-    const int32_t j = act ? col[e] : (int32_t)row;
-    const int64_t oj = orig[j];
-    double t2 = 0.0, g2 = 0.0;
-    if (use_t) {
-      const bool skip = nti || (notarl[j] != 0);
-      t2 = (TK > 0) ? sqdist16_reg<TK>(fti, tarl + oj * tdim, t) : sqdist16(tarl + oi * tdim, tarl + oj * tdim, tdim, t);
-      if (skip) t2 = 0.0;
+  // 64 edges per round: sixteen passes of four edges (16 lanes each) leave the squared feature distance
+  // of edge eb + 4 q + grp in every lane of group grp; lane (grp, t) keeps the one of pass q = t, so that
+  // afterwards EVERY lane owns one edge and the sqrt / exp epilogue (the bulk of the instructions) runs
+  // with all 64 lanes busy instead of one lane per edge
+  for (int32_t eb = e0; eb < e1; eb += 64) {
+    double my_t2 = 0.0, my_g2 = 0.0;
+#pragma unroll 4
+    for (int q = 0; q < 16; ++q) {
+      if (eb + 4 * q >= e1) break;  // wave-uniform
+      const int32_t e = eb + 4 * q + grp;
+      const bool act = e < e1;
+      const int32_t j = act ? col[e] : (int32_t)row;
+      const int64_t oj = orig[j];
+      double t2 = 0.0, g2 = 0.0;
+      if (use_t) {
+        const bool skip = nti || (notarl[j] != 0);
+        t2 = (TK > 0) ? sqdist16_reg<TK>(fti, tarl + oj * tdim, t) : sqdist16(tarl + oi * tdim, tarl + oj * tdim, tdim, t);
+        if (skip) t2 = 0.0;
+      }
+      if (use_d) g2 = (DK > 0) ? sqdist16_reg<DK>(fdi, dino + oj * ddim, t) : sqdist16(dino + oi * ddim, dino + oj * ddim, ddim, t);
+      if (t == q) {
+        my_t2 = t2;
+        my_g2 = g2;
+      }
     }
-    if (use_d) g2 = (DK > 0) ? sqdist16_reg<DK>(fdi, dino + oj * ddim, t) : sqdist16(dino + oi * ddim, dino + oj * ddim, ddim, t);
-    if (act && t == 0) {
+    const int32_t e = eb + 4 * t + grp;
+    if (e < e1) {
       const double d = val[e];
       double w = 1.0;
-      if (use_t) w = exp(-theta * sqrt(t2));
+      if (use_t) w = exp(-theta * sqrt(my_t2));
       if (alpha != 0.0) w = w * exp(-alpha * d);
-      if (use_d) w = w * exp(-gamma * sqrt(g2));
+      if (use_d) w = w * exp(-gamma * sqrt(my_g2));
       val[e] = w;
     }
   }
@@ -433,7 +450,9 @@ extern "C" int ai_affinity_build(ai_ctx* ctx, const double* xyz, int64_t n, cons
   }
   {
     const unsigned gw = (unsigned)((n + (AI_BLOCK / 64) - 1) / (AI_BLOCK / 64));
-    const bool t96 = (d_tarl == nullptr) || tarl_dim == 96, d384 = (d_dino == nullptr) || dino_dim == 384;
+    // the row's own features stay in registers when the width is the reference's (96-d TARL, 384-d DINO);
+    // an absent factor takes the width-0 instantiation so that it costs no registers
+    const bool t96 = d_tarl != nullptr && tarl_dim == 96, d384 = d_dino != nullptr && dino_dim == 384;
 #define AI_LAUNCH_W(TK, DK)                                                                                                          \
   hipLaunchKernelGGL((k_weights<TK, DK>), dim3(gw), dim3(AI_BLOCK), 0, st, (const int32_t*)A->rowptr, (const int32_t*)A->col, A->val, \
                      (const int32_t*)A->orig, n, d_tarl, tarl_dim, (const uint8_t*)notarl.p, d_dino, dino_dim, alpha, theta, gamma)
@@ -441,6 +460,8 @@ extern "C" int ai_affinity_build(ai_ctx* ctx, const double* xyz, int64_t n, cons
       AI_LAUNCH_W(6, 24);
     else if (t96)
       AI_LAUNCH_W(6, 0);
+    else if (d384)
+      AI_LAUNCH_W(0, 24);
     else
       AI_LAUNCH_W(0, 0);
 #undef AI_LAUNCH_W
