@@ -2064,8 +2064,6 @@ class Solver {
     AI_KERNEL_CHECK();
     hipLaunchKernelGGL(k_seg_sum, dim3(S_), dim3(AI_BLOCK), 0, st, fine.d_seg0.p, pvol.p, s_vol.p);
     AI_KERNEL_CHECK();
-    hipLaunchKernelGGL(k_scale, dim3(fine.n), dim3(AI_BLOCK), 0, st, fine.d.p, rowptr, col, wraw, deg.p, sinv.p, s_vol.p, wm.p, sinv2.p, u1.p);
-    AI_KERNEL_CHECK();
     std::vector<int32_t> ncomp(S_, 1);
     if (want_cc) {
       bool any = false;
@@ -2113,6 +2111,12 @@ class Solver {
     pk.add(&factive.p, ones.data(), (size_t)lzf.n);
     pk.add(&cactive.p, ones.data(), (size_t)lzc.n);
     AI_TRY(pk.flush(blobB, st));
+    // scaled matrix, 1 / deg and u1 are only read by the Lanczos kernels: rows of null-vector segments skip them
+    if (lzf.n > 0) {
+      hipLaunchKernelGGL(k_scale, dim3(lzf.n), dim3(AI_BLOCK), 0, st, (const Task*)lzf.d.p, rowptr, col, wraw, deg.p, sinv.p, s_vol.p, wm.p,
+                         sinv2.p, u1.p);
+      AI_KERNEL_CHECK();
+    }
     if (enc_min_tasks < 0) {
       const char* v = getenv("AI_SPMV_STAGE_MIN");
       enc_min_tasks = v ? atoi(v) : 0;

@@ -48,6 +48,22 @@ def spmv_bytes(rows: int, nnz: int, launches: int) -> float:
     return nnz * 12.0 + rows * (4.0 + 3 * 8.0) + launches * 4.0
 
 
+def pmc_traffic(batch: int):
+    """HBM-side bytes per SpMV launch from the committed PMC passes (`profiles/r01_pmc_traffic.json`:
+    rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of the same batched call, corrected
+    as MI355X_MICROARCH.md prescribes).  Counters cannot be read inside this process, so the number is
+    only reported when it was measured for the same chunks-per-batch; otherwise null."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            r = json.load(f)
+    except (OSError, ValueError):
+        return None, None
+    if f" {batch} 1" not in r.get("command", ""):
+        return None, None
+    return r.get("traffic_bytes_per_launch"), "profiles/r01_pmc_traffic_summary.txt"
+
+
 def cpu_baseline(seconds_budget: float = 30.0):
     """Oracle on a bounded sample: one 20 000-point chunk of the same generator and config."""
     from autoinst_amd import synth
@@ -173,6 +189,7 @@ def main():
         launches = int(stp["lanczos_steps"])
         b = spmv_bytes(int(stp["spmv_rows"]), int(stp["spmv_nnz"]), launches)
         ach = b / (stp["ms_spmv"] * 1e-3) / 1e9 if stp["ms_spmv"] > 0 else 0.0
+        traffic, traffic_src = pmc_traffic(B)
         out = {
             "metric": "chunks/sec (200k-pt TARL+Spatial NCuts chunk: affinity build + recursive normalized cut)",
             "value": world * K * B * args.steps / elapsed,
@@ -209,7 +226,8 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBPS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "launches": launches,
                 "avg_launch_us": 1e3 * stp["ms_spmv"] / max(launches, 1),
                 "bytes_per_launch_avg": b / max(launches, 1),

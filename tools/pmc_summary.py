@@ -1,0 +1,41 @@
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (csv) per kernel.
+
+    python tools/pmc_summary.py <fetch dir> <write dir> <out prefix> "<command that was profiled>"
+writes <out>_summary.txt and <out>.json (per-launch means for the dominant SpMV kernel, corrected as
+MI355X_MICROARCH.md prescribes: FETCH_SIZE is reported in KB and, on gfx950, counts 64 B per 128-B
+request of a coalesced stream, i.e. half the bytes: x2; WRITE_SIZE is exact).
+"""
+import csv, glob, json, sys, collections
+
+def load(d, counter):
+    f = glob.glob(d + "/**/*_counter_collection.csv", recursive=True)[0]
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        n = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
+        agg[n].append(float(r["Counter_Value"]))
+    return agg
+
+fd, wd, out, cmd = sys.argv[1:5]
+F, W = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
+lines = [f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `{cmd}`.",
+         "Units: KB as rocprofv3 reports them.  FETCH_SIZE = TCC_EA0_RDREQ x 64 B: on gfx950 a wide coalesced stream reads 2x this",
+         "(MI355X_MICROARCH.md); Infinity-Cache hits are counted (L2-side requests), so this is L2<->fabric traffic, an upper bound of HBM traffic.", ""]
+for name, agg in (("FETCH_SIZE", F), ("WRITE_SIZE", W)):
+    lines.append(f"{'kernel':44s} {'counter':12s} {'launches':>9s} {'sum_KB':>14s} {'mean_KB':>12s} {'max_KB':>12s}")
+    for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:10]:
+        lines.append(f"{k[:44]:44s} {name:12s} {len(v):9d} {sum(v):14.1f} {sum(v)/len(v):12.2f} {max(v):12.2f}")
+    lines.append("")
+spmv = [k for k in F if k.startswith("void k_lz_spmv") or k.startswith("k_lz_spmv")]
+res = {}
+if spmv:
+    k = max(spmv, key=lambda x: sum(F[x]))
+    fm = sum(F[k]) / len(F[k]) * 1024.0
+    wm = sum(W.get(k, [0.0])) / max(len(W.get(k, [])), 1) * 1024.0
+    res = {"kernel": k, "launches": len(F[k]), "fetch_raw_bytes_per_launch": fm, "write_bytes_per_launch": wm,
+           "traffic_bytes_per_launch": 2.0 * fm + wm, "command": cmd}
+    lines.append(f"{k}: mean FETCH_SIZE {fm/1e6:.2f} MB raw per launch (x2 = {2*fm/1e6:.2f} MB), WRITE_SIZE {wm/1e6:.2f} MB -> traffic {res['traffic_bytes_per_launch']/1e6:.2f} MB per launch")
+open(out + "_summary.txt", "w").write("\n".join(lines) + "\n")
+json.dump(res, open(out + ".json", "w"), indent=1)
+print("\n".join(lines))
