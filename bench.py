@@ -113,8 +113,6 @@ def main():
     from autoinst_amd import ncuts_api as api
     from autoinst_amd import sharding, synth
 
-    from concurrent.futures import ThreadPoolExecutor
-
     K = max(1, args.in_flight)   # host threads per rank, each with its own context (HIP streams + workspace)
     B = max(1, args.batch)       # chunks per ai_ncut_batch call: root segments of one frontier
     dev = torch.device("cuda", local_rank)
@@ -127,7 +125,6 @@ def main():
         ch = synth.synthetic_chunk(N_POINTS, seed=i, tarl=True)
         data.append((torch.from_numpy(ch["points"]).to(dev), torch.from_numpy(ch["tarl"]).to(dev)))
     torch.cuda.synchronize()
-    pool = ThreadPoolExecutor(max_workers=K)
 
     def one_batch(k, profile=False, only_first=False):
         mine = data[k * B:(k + 1) * B][: 1 if only_first else B]
@@ -144,25 +141,49 @@ def main():
                 g.free()
         return labs, ngs, st, nnz
 
-    def step():
-        # the library calls release the GIL, so the K batches really are in flight together
-        res = list(pool.map(one_batch, range(K)))
-        local = {(rank * K + k) * B + b: res[k][0][b] for k in range(K) for b in range(B)}
-        merged = sharding.gather_labels(local, device=dev) if world > 1 else local
-        return res, merged
+    def run_steps(nsteps):
+        """`nsteps` steps: every host thread pushes `nsteps` batches back to back (the library calls release
+        the GIL, so the K batches really are in flight together, and a thread does not wait for the others
+        between steps); this thread takes each step's K results as they complete and (N > 1) gathers that
+        step's label arrays to rank 0.  Returns the last step's results."""
+        import queue
+        import threading
+        qs = [queue.Queue() for _ in range(K)]
+
+        def worker(k):
+            for _ in range(nsteps):
+                try:
+                    qs[k].put(one_batch(k))
+                except BaseException as e:  # surface the failure in the consuming thread
+                    qs[k].put(e)
+                    return
+
+        th = [threading.Thread(target=worker, args=(k,)) for k in range(K)]
+        for t in th:
+            t.start()
+        last = None
+        for _ in range(nsteps):
+            res = [q.get() for q in qs]
+            for r in res:
+                if isinstance(r, BaseException):
+                    raise r
+            local = {(rank * K + k) * B + b: res[k][0][b] for k in range(K) for b in range(B)}
+            merged = sharding.gather_labels(local, device=dev) if world > 1 else local
+            last = (res, merged)
+        for t in th:
+            t.join()
+        return last
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    if args.warmup > 0:
+        run_steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    last = None
-    for _ in range(args.steps):
-        last = step()
+    last = run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
