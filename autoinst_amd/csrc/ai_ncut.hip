@@ -551,114 +551,6 @@ __global__ __launch_bounds__(AI_BLOCK) void k_lz_spmv_x(const Task* __restrict__
   if (threadIdx.x == 0) pA[t] = tot;
 }
 
-// Flat form of the staged kernel: the task's entries are read as ONE contiguous, aligned stream
-// (every lane busy, no rowptr -> entry dependency), the products go to LDS, and the rows are summed
-// from LDS (16 lanes per row).  Products are rounded before they are added, so the last bits differ
-// from the fma chain of the row-structured kernels; the order is fixed, results are reproducible.
-#define AI_FLAT_UNROLL 4
-template <int LPR, int ILP>
-__global__ __launch_bounds__(AI_BLOCK) void k_lz_spmv_f(const Task* __restrict__ ftasks, const int32_t* __restrict__ factive, int ntask,
-                                                        const TaskEnc* __restrict__ enc, const int32_t* __restrict__ ucol,
-                                                        const uint16_t* __restrict__ lidx, const int32_t* __restrict__ rowptr,
-                                                        const int32_t* __restrict__ col, const double* __restrict__ wm,
-                                                        const double* __restrict__ sinv2, const double* __restrict__ Rj,
-                                                        double* __restrict__ Z, double* __restrict__ pA) {
-  __shared__ double sm[AI_BLOCK / 64];
-  __shared__ double xs[AI_ENC_XCAP];
-  __shared__ double prod[AI_ENC_MAXNNZ];
-  const int t = ai_xcd_task(blockIdx.x, ntask);
-  const int act = factive[t];
-  const Task tk = ftasks[t];
-  const TaskEnc en = enc[t];
-  if (!act) return;
-  if (en.ucnt < 0) {
-    spmv_body<LPR, ILP>(t, ftasks, factive, rowptr, col, wm, sinv2, Rj, Z, pA, sm);
-    return;
-  }
-  const int P0 = rowptr[tk.x], cnt = rowptr[tk.y] - P0;
-  for (int i = threadIdx.x; i < en.ucnt; i += AI_BLOCK) xs[i] = Rj[ucol[en.uoff + i]];
-  const int l = threadIdx.x & (LPR - 1), r = threadIdx.x / LPR;
-  constexpr int GROUPS = AI_BLOCK / LPR;
-  int a0[ILP], a1[ILP];
-  double ri[ILP], s2[ILP];
-#pragma unroll
-  for (int u = 0; u < ILP; ++u) {
-    const int row = tk.x + r + u * GROUPS;
-    const bool ok = row < tk.y;
-    a0[u] = ok ? rowptr[row] - P0 : 0;
-    a1[u] = ok ? rowptr[row + 1] - P0 : 0;
-    ri[u] = (ok && l == 0) ? Rj[row] : 0.0;
-    s2[u] = (ok && l == 0) ? sinv2[row] : 0.0;
-  }
-  int c[AI_FLAT_UNROLL];
-  double w[AI_FLAT_UNROLL];
-#pragma unroll
-  for (int q = 0; q < AI_FLAT_UNROLL; ++q) {  // first round: independent of xs, in flight across the barrier
-    const int e = threadIdx.x + q * AI_BLOCK;
-    const bool ok = e < cnt;
-    c[q] = ok ? (int)lidx[P0 + e] : 0;
-    w[q] = ok ? wm[P0 + e] : 0.0;
-  }
-  __syncthreads();
-  for (int e0 = 0; e0 < cnt; e0 += AI_FLAT_UNROLL * AI_BLOCK) {
-    int cn[AI_FLAT_UNROLL];
-    double wn[AI_FLAT_UNROLL];
-#pragma unroll
-    for (int q = 0; q < AI_FLAT_UNROLL; ++q) {
-      const int e = e0 + AI_FLAT_UNROLL * AI_BLOCK + threadIdx.x + q * AI_BLOCK;
-      const bool ok = e < cnt;
-      cn[q] = ok ? (int)lidx[P0 + e] : 0;
-      wn[q] = ok ? wm[P0 + e] : 0.0;
-    }
-#pragma unroll
-    for (int q = 0; q < AI_FLAT_UNROLL; ++q) {
-      const int e = e0 + threadIdx.x + q * AI_BLOCK;
-      if (e < cnt) prod[e] = w[q] * xs[c[q]];
-    }
-#pragma unroll
-    for (int q = 0; q < AI_FLAT_UNROLL; ++q) {
-      c[q] = cn[q];
-      w[q] = wn[q];
-    }
-  }
-  __syncthreads();
-  double acc = 0.0;
-#pragma unroll
-  for (int u = 0; u < ILP; ++u) {
-    double sg = 0.0;
-    for (int k = a0[u] + l; k < a1[u]; k += LPR) sg += prod[k];
-#pragma unroll
-    for (int o = LPR / 2; o > 0; o >>= 1) sg += __shfl_xor(sg, o, LPR);
-    const int row = tk.x + r + u * GROUPS;
-    if (l == 0 && row < tk.y) {
-      const double z = fma(s2[u], ri[u], sg);
-      Z[row] = z;
-      acc = fma(ri[u], z, acc);
-    }
-  }
-  const double tot = ai_block_sum(acc, sm);
-  if (threadIdx.x == 0) pA[t] = tot;
-}
-
-
-// experiment: TPB consecutive fine tasks per block, back to back (neighbouring rows share most of
-// their gathered entries, so the block's L1 lines are re-used)
-
-template <int TPB>
-__global__ __launch_bounds__(AI_BLOCK) void k_lz_spmv_multi(const Task* __restrict__ ftasks, const int32_t* __restrict__ factive, int ntask,
-                                                            const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                                            const double* __restrict__ wm, const double* __restrict__ sinv2,
-                                                            const double* __restrict__ Rj, double* __restrict__ Z,
-                                                            double* __restrict__ pA) {
-  __shared__ double sm[AI_BLOCK / 64];
-  const int nblk = (ntask + TPB - 1) / TPB;
-  const int b = ai_xcd_task(blockIdx.x, nblk);
-  for (int q = 0; q < TPB; ++q) {
-    const int t = b * TPB + q;
-    if (t < ntask) spmv_body<16, AI_ROW_ILP>(t, ftasks, factive, rowptr, col, wm, sinv2, Rj, Z, pA, sm);
-  }
-}
-
 struct LzSeg {
   int32_t* frozen;      // [S]
   int32_t* m;           // [S] size of T at freeze
@@ -2201,30 +2093,10 @@ class Solver {
     }
     switch (spmv_variant) {
       case 9: return launch_spmv_t<16, AI_ROW_ILP, true>(j, e0, e1);  // timing only: no gather of R_j (wrong results)
-      case 6:
-      case 7: {
-        const int tpb = spmv_variant == 6 ? 4 : 2;
-        const unsigned nb = (unsigned)((lzf.n + tpb - 1) / tpb);
-        if (tpb == 4)
-          hipLaunchKernelGGL((k_lz_spmv_multi<4>), dim3(nb), dim3(AI_BLOCK), 0, st, (const Task*)lzf.d.p, (const int32_t*)factive.p, lzf.n, rowptr,
-                             col, (const double*)wm.p, (const double*)sinv2.p, (const double*)vec(j), Y.p, pA.p);
-        else
-          hipLaunchKernelGGL((k_lz_spmv_multi<2>), dim3(nb), dim3(AI_BLOCK), 0, st, (const Task*)lzf.d.p, (const int32_t*)factive.p, lzf.n, rowptr,
-                             col, (const double*)wm.p, (const double*)sinv2.p, (const double*)vec(j), Y.p, pA.p);
-        AI_KERNEL_CHECK();
-        return AI_OK;
-      }
       case 1: return launch_spmv_t<16, AI_ROW_ILP>(j, e0, e1);  // plain gather from global memory
       default: break;
     }
     if (!enc_ready) return launch_spmv_t<16, AI_ROW_ILP>(j, e0, e1);
-    if (spmv_variant == 2) {
-      hipExtLaunchKernelGGL((k_lz_spmv_f<16, AI_ROW_ILP>), dim3(lzf.n), dim3(AI_BLOCK), 0, st, e0, e1, 0, (const Task*)lzf.d.p,
-                            (const int32_t*)factive.p, lzf.n, (const TaskEnc*)enc.p, (const int32_t*)ucol.p, (const uint16_t*)lidx.p, rowptr, col,
-                            (const double*)wm.p, (const double*)sinv2.p, (const double*)vec(j), Y.p, pA.p);
-      AI_KERNEL_CHECK();
-      return AI_OK;
-    }
     if (e0) {
       hipExtLaunchKernelGGL((k_lz_spmv_x<16, AI_ROW_ILP>), dim3(lzf.n), dim3(AI_BLOCK), 0, st, e0, e1, 0, (const Task*)lzf.d.p,
                             (const int32_t*)factive.p, lzf.n, (const TaskEnc*)enc.p, (const int32_t*)ucol.p, (const uint16_t*)lidx.p, rowptr, col,

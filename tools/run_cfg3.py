@@ -8,8 +8,9 @@ Launch with one rank per GPU:
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/run_cfg3.py
     python tools/run_cfg3.py --small            # 1 GPU, reduced map (used by the GPU test suite)
 
-Chunks are assigned by LPT (autoinst_amd.sharding), each rank keeps `--in-flight` chunks going,
-label arrays are gathered to rank 0 (RCCL), which prints one JSON line.
+Chunks are assigned by LPT (autoinst_amd.sharding), each rank runs `--in-flight` host threads that
+push `--batch` chunks per batched call, label arrays are gathered to rank 0 (RCCL), which prints
+one JSON line.
 """
 import argparse, json, os, sys, time
 from concurrent.futures import ThreadPoolExecutor
@@ -26,31 +27,33 @@ def chunk_sizes(small: bool):
     return [int(x) for x in np.exp(rng.uniform(np.log(3000), np.log(30000), 64))] + [200_000] * 8
 
 
-def run_map(sizes, world, rank, local_rank, in_flight=4, dist=None, dev=None):
+def run_map(sizes, world, rank, local_rank, in_flight=4, dist=None, dev=None, batch=6):
     from autoinst_amd import ncuts_api as api, sharding, synth
     mine = sharding.lpt_assign(sizes, world)[rank]
     ctxs = [api.Context(local_rank) for _ in range(in_flight)]
     data = {i: synth.synthetic_chunk(sizes[i], seed=1000 + i, tarl=True) for i in mine}
 
-    def work(job):
-        slot, i = job
-        ch = data[i]
-        groups_lab, ng, st = None, None, None
-        g = api.build_affinity(ch["points"], ch["tarl"], alpha=1.0, theta=0.5, gamma=0.0, ctx=ctxs[slot])
+    def work(slot, ids):
+        """One batched call: the chunks are root segments of one frontier (ai_ncut_batch)."""
+        graphs = [api.build_affinity(data[i]["points"], data[i]["tarl"], alpha=1.0, theta=0.5, gamma=0.0, ctx=ctxs[slot]) for i in ids]
         try:
-            lab, ng, st = api.ncuts_labels(g, sizes[i], 0.03)
+            labs, ngs, st = api.ncuts_labels_batch(graphs, None, 0.03)
         finally:
-            g.free()
-        return i, lab
+            for g in graphs:
+                g.free()
+        return list(zip(ids, labs))
 
-    # largest first; slot = position modulo the number of contexts (a context serves one chunk at a time)
+    # largest first, dealt round-robin to the host threads; a thread pushes `batch` chunks per call
     order = sorted(mine, key=lambda i: -sizes[i])
     t0 = time.perf_counter()
     out = {}
     with ThreadPoolExecutor(max_workers=in_flight) as pool:
         lanes = [order[k::in_flight] for k in range(in_flight)]
         def lane(k):
-            return [work((k, i)) for i in lanes[k]]
+            res = []
+            for j in range(0, len(lanes[k]), batch):
+                res += work(k, lanes[k][j:j + batch])
+            return res
         for res in pool.map(lane, range(in_flight)):
             for i, lab in res:
                 out[i] = lab
@@ -61,7 +64,8 @@ def run_map(sizes, world, rank, local_rank, in_flight=4, dist=None, dev=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--small", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=4)
+    ap.add_argument("--in-flight", type=int, default=4, help="host threads (contexts) per GPU")
+    ap.add_argument("--batch", type=int, default=6, help="chunks per batched call")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -71,7 +75,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
     sizes = chunk_sizes(args.small)
-    merged, dt = run_map(sizes, world, rank, local, args.in_flight, dist, dev)
+    merged, dt = run_map(sizes, world, rank, local, args.in_flight, dist, dev, args.batch)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
     if rank == 0:
