@@ -401,8 +401,8 @@ extern "C" int ai_affinity_build(ai_ctx* ctx, const double* xyz, int64_t n, cons
     }                                                                                     \
   } while (0)
 
-  AI_HIPF(hipMalloc((void**)&A->orig, (size_t)n * sizeof(int32_t)));
-  AI_HIPF(hipMalloc((void**)&A->rowptr, (size_t)(n + 1) * sizeof(int32_t)));
+  AI_HIPF(ctx->graphs.alloc((void**)&A->orig, (size_t)n * sizeof(int32_t)));
+  AI_HIPF(ctx->graphs.alloc((void**)&A->rowptr, (size_t)(n + 1) * sizeof(int32_t)));
   {
     size_t tmp_bytes = 0;
     AI_HIPF(rocprim::radix_sort_pairs(nullptr, tmp_bytes, key.p, key2.p, idx.p, A->orig, (size_t)n, 0, 30, st));
@@ -437,8 +437,8 @@ extern "C" int ai_affinity_build(ai_ctx* ctx, const double* xyz, int64_t n, cons
     return fail(AI_ERR_INTERNAL);
   }
   A->nnz = nnz32;
-  AI_HIPF(hipMalloc((void**)&A->col, (size_t)A->nnz * sizeof(int32_t)));
-  AI_HIPF(hipMalloc((void**)&A->val, (size_t)A->nnz * sizeof(double)));
+  AI_HIPF(ctx->graphs.alloc((void**)&A->col, (size_t)A->nnz * sizeof(int32_t)));
+  AI_HIPF(ctx->graphs.alloc((void**)&A->val, (size_t)A->nnz * sizeof(double)));
   hipLaunchKernelGGL(k_neighbours<true>, dim3(gb), dim3(AI_BLOCK), 0, st, X.p, Y.p, Z.p, cellid.p, cstart.p, cend.p, n, g,
                      radius, (int32_t*)nullptr, (const int32_t*)A->rowptr, A->col, A->val);
   AI_HIPF(hipGetLastError());

@@ -45,6 +45,60 @@ void ai_arena::release_all() {
   blocks.clear();
   cur = off = 0;
 }
+hipError_t ai_graph_cache::alloc(void** out, size_t bytes) {
+  bytes = (bytes + ((size_t)1 << 16) - 1) & ~(((size_t)1 << 16) - 1);
+  // best fit among the kept buffers, at most 25 % (+1 MB) larger than asked for
+  int best = -1;
+  for (int i = 0; i < (int)free_list.size(); ++i)
+    if (free_list[i].cap >= bytes && free_list[i].cap <= bytes + bytes / 4 + ((size_t)1 << 20) &&
+        (best < 0 || free_list[i].cap < free_list[best].cap))
+      best = i;
+  if (best >= 0) {
+    live.push_back(free_list[best]);
+    cached_bytes -= free_list[best].cap;
+    *out = free_list[best].p;
+    free_list.erase(free_list.begin() + best);
+    return hipSuccess;
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess && !free_list.empty()) {  // give the kept buffers back and try once more
+    for (auto& b : free_list) (void)hipFree(b.p);
+    free_list.clear();
+    cached_bytes = 0;
+    e = hipMalloc(&p, bytes);
+  }
+  if (e != hipSuccess) return e;
+  live.push_back(Block{p, bytes});
+  *out = p;
+  return hipSuccess;
+}
+
+void ai_graph_cache::release(void* p) {
+  if (!p) return;
+  for (size_t i = 0; i < live.size(); ++i)
+    if (live[i].p == p) {
+      const Block b = live[i];
+      live.erase(live.begin() + i);
+      if (cached_bytes + b.cap > max_cached_bytes) {
+        (void)hipFree(b.p);
+      } else {
+        free_list.push_back(b);
+        cached_bytes += b.cap;
+      }
+      return;
+    }
+  (void)hipFree(p);  // not one of ours (a graph built by another context)
+}
+
+void ai_graph_cache::release_all() {
+  for (auto& b : free_list) (void)hipFree(b.p);
+  for (auto& b : live) (void)hipFree(b.p);
+  free_list.clear();
+  live.clear();
+  cached_bytes = 0;
+}
+
 extern "C" int ai_version(void) { return 100; }
 
 extern "C" int ai_ctx_create(int device, ai_ctx** out) {
@@ -101,6 +155,7 @@ extern "C" int ai_ctx_destroy(ai_ctx* ctx) {
   if (ctx->lz_args_dev) (void)hipFree(ctx->lz_args_dev);
   if (ctx->lz_step_dev) (void)hipFree(ctx->lz_step_dev);
   ctx->arena.release_all();
+  ctx->graphs.release_all();  // graphs still alive lose their buffers with the context that built them
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return AI_OK;
@@ -108,11 +163,14 @@ extern "C" int ai_ctx_destroy(ai_ctx* ctx) {
 
 extern "C" int ai_csr_free(ai_ctx* ctx, ai_csr* csr) {
   if (!csr) return AI_OK;
-  if (ctx) (void)hipSetDevice(ctx->device);
-  if (csr->rowptr) (void)hipFree(csr->rowptr);
-  if (csr->col) (void)hipFree(csr->col);
-  if (csr->val) (void)hipFree(csr->val);
-  if (csr->orig) (void)hipFree(csr->orig);
+  if (ctx) {
+    (void)hipSetDevice(ctx->device);
+    ctx->graphs.release(csr->rowptr);
+    ctx->graphs.release(csr->col);
+    ctx->graphs.release(csr->val);
+    ctx->graphs.release(csr->orig);
+  }  // without a context only the handle goes: the buffers belong to the context that built the graph
+     // and are released with it at the latest
   delete csr;
   return AI_OK;
 }
@@ -160,9 +218,9 @@ extern "C" int ai_csr_from_host(ai_ctx* ctx, int64_t n, const int64_t* indptr, c
   A->val = nullptr;
   A->orig = nullptr;
   A->device = ctx->device;
-  hipError_t e1 = hipMalloc((void**)&A->rowptr, (size_t)(n + 1) * sizeof(int32_t));
-  hipError_t e2 = hipMalloc((void**)&A->col, (size_t)(nnz > 0 ? nnz : 1) * sizeof(int32_t));
-  hipError_t e3 = hipMalloc((void**)&A->val, (size_t)(nnz > 0 ? nnz : 1) * sizeof(double));
+  hipError_t e1 = ctx->graphs.alloc((void**)&A->rowptr, (size_t)(n + 1) * sizeof(int32_t));
+  hipError_t e2 = ctx->graphs.alloc((void**)&A->col, (size_t)(nnz > 0 ? nnz : 1) * sizeof(int32_t));
+  hipError_t e3 = ctx->graphs.alloc((void**)&A->val, (size_t)(nnz > 0 ? nnz : 1) * sizeof(double));
   if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
     ai_csr_free(ctx, A);
     ai_set_error("ai_csr_from_host: device allocation failed");

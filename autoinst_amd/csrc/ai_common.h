@@ -63,6 +63,22 @@ struct ArenaScope {
 #define AI_PINNED_INTS 4096
 #define AI_CHECK_DEPTH 16
 #define AI_STAGE_BYTES ((size_t)8 << 20)
+// Device buffers of the graphs a context hands out (ai_csr): hipFree synchronises the whole device,
+// which with several host threads stalls every other thread's stream, so freed buffers are kept and
+// re-used by the next graph of similar size.
+struct ai_graph_cache {
+  struct Block {
+    void* p;
+    size_t cap;
+  };
+  std::vector<Block> free_list, live;
+  size_t cached_bytes = 0;
+  size_t max_cached_bytes = (size_t)32 << 30;
+  hipError_t alloc(void** out, size_t bytes);
+  void release(void* p);
+  void release_all();
+};
+
 struct ai_ctx {
   int device;
   hipStream_t stream;
@@ -73,6 +89,7 @@ struct ai_ctx {
   hipEvent_t chk_ev1[AI_CHECK_DEPTH];  // main stream -> side stream hand-off of a check's inputs
   hipStream_t side;                    // convergence checks run here, beside the Lanczos steps
   ai_arena arena;                      // call-scoped device workspace, kept between calls
+  ai_graph_cache graphs;               // buffers of the graphs this context built
   char* stage;                         // AI_STAGE_BYTES of pinned host memory for packed small uploads / downloads
   // replayable Lanczos batches: the graph kernels read their arguments from lz_args_dev and the
   // step index from lz_step_dev, so one instantiated graph per grid size serves every level / chunk

@@ -80,6 +80,11 @@ int ai_csr_dims(const ai_csr* csr, int64_t* n, int64_t* nnz);
  */
 int ai_csr_export(ai_ctx* ctx, const ai_csr* csr, int64_t* indptr, int32_t* indices, double* data);
 
+/*
+ * Release a graph.  `ctx` must be the context that built it: the device buffers go back to that
+ * context's cache (hipFree would synchronise the whole device and stall other host threads) and are
+ * re-used by its next graph of similar size; everything is returned to the driver by ai_ctx_destroy.
+ */
 int ai_csr_free(ai_ctx* ctx, ai_csr* csr);
 
 typedef struct {
