@@ -132,8 +132,6 @@ extern "C" int ai_ctx_create(int device, ai_ctx** out) {
   }
   AI_HIP(hipHostMalloc((void**)&c->pinned, AI_PINNED_INTS * sizeof(int32_t), hipHostMallocDefault));
   AI_HIP(hipHostMalloc((void**)&c->stage, AI_STAGE_BYTES, hipHostMallocDefault));
-  AI_HIP(hipMalloc(&c->lz_args_dev, 4096));
-  AI_HIP(hipMalloc((void**)&c->lz_step_dev, 64));
   *out = c;
   return AI_OK;
 }
@@ -151,9 +149,6 @@ extern "C" int ai_ctx_destroy(ai_ctx* ctx) {
   (void)hipStreamDestroy(ctx->side);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->stage) (void)hipHostFree(ctx->stage);
-  for (auto& g : ctx->lz_graphs) (void)hipGraphExecDestroy(g.exec);
-  if (ctx->lz_args_dev) (void)hipFree(ctx->lz_args_dev);
-  if (ctx->lz_step_dev) (void)hipFree(ctx->lz_step_dev);
   ctx->arena.release_all();
   ctx->graphs.release_all();  // graphs still alive lose their buffers with the context that built them
   (void)hipStreamDestroy(ctx->stream);

@@ -91,15 +91,6 @@ struct ai_ctx {
   ai_arena arena;                      // call-scoped device workspace, kept between calls
   ai_graph_cache graphs;               // buffers of the graphs this context built
   char* stage;                         // AI_STAGE_BYTES of pinned host memory for packed small uploads / downloads
-  // replayable Lanczos batches: the graph kernels read their arguments from lz_args_dev and the
-  // step index from lz_step_dev, so one instantiated graph per grid size serves every level / chunk
-  void* lz_args_dev;
-  int32_t* lz_step_dev;
-  struct GraphEntry {
-    int grid_f, grid_c;
-    hipGraphExec_t exec;
-  };
-  std::vector<GraphEntry> lz_graphs;
 };
 
 struct ai_csr {

@@ -690,59 +690,6 @@ __global__ __launch_bounds__(AI_BLOCK) void k_lz_update(const Task* __restrict__
   update_body(blockIdx.x, ctasks, cranges, L, j, pA, pBcur, pBnext, u1, Z, Rj, Rjm1, Rnext, sm3);
 }
 
-// ---- graph-replayable forms: every level-specific value comes from one device-resident block, and
-// the step index from two device counters, so that ONE instantiated hipGraph of AI_GRAPH_STEPS steps
-// serves every level of every chunk (one API call per 16 steps instead of 32 launches).
-#define AI_GRAPH_STEPS 16
-struct LzArgs {
-  const Task* ftasks;
-  const Task* ctasks;
-  const TaskRange* cranges;
-  const TaskRange* segrange;
-  const int32_t* mode;
-  const int32_t* rowptr;
-  const int32_t* col;
-  const double* wm;
-  const double* sinv2;
-  const double* u1;
-  double* Z;
-  double* pA;
-  double2* pB0;
-  double2* pB1;
-  double* const* slabs;
-  double* bnew;  // [AI_CHECK_DEPTH][S + 1]
-  int32_t* step;  // [0]: step of the next SpMV, [1]: step of the next update
-  size_t stride;
-  LzSeg L;
-  int nft, nct, S;
-};
-
-__global__ __launch_bounds__(AI_BLOCK) void k_lz_spmv_g(const LzArgs* __restrict__ A) {
-  __shared__ double sm[AI_BLOCK / 64];
-  const int j = A->step[0];
-  if (blockIdx.x == 0 && threadIdx.x == 0) A->step[1] = j;  // nobody reads step[1] during this launch
-  const int nft = A->nft;
-  if (j >= A->L.mcap || (int)blockIdx.x >= nft) return;
-  const double* Rj = A->slabs[j / AI_SLAB_VECS] + (size_t)(j % AI_SLAB_VECS) * A->stride;
-  spmv_body<16, AI_ROW_ILP>(ai_xcd_task(blockIdx.x, nft), A->ftasks, A->L.factive, A->rowptr, A->col, A->wm, A->sinv2, Rj, A->Z, A->pA, sm);
-}
-
-__global__ __launch_bounds__(AI_BLOCK) void k_lz_update_g(const LzArgs* __restrict__ A) {
-  __shared__ double sm3[3][AI_BLOCK / 64];
-  const int j = A->step[1];
-  if (blockIdx.x == 0 && threadIdx.x == 0) A->step[0] = j + 1;  // nobody reads step[0] during this launch
-  if (j >= A->L.mcap || (int)blockIdx.x >= A->nct) return;
-  const size_t st = A->stride;
-  double* const* sl = A->slabs;
-  const double* Rj = sl[j / AI_SLAB_VECS] + (size_t)(j % AI_SLAB_VECS) * st;
-  const int jm = j > 0 ? j - 1 : 0;
-  const double* Rjm1 = sl[jm / AI_SLAB_VECS] + (size_t)(jm % AI_SLAB_VECS) * st;
-  double* Rn = sl[(j + 1) / AI_SLAB_VECS] + (size_t)((j + 1) % AI_SLAB_VECS) * st;
-  const double2* pBcur = (j & 1) ? A->pB1 : A->pB0;
-  double2* pBnext = (j & 1) ? A->pB0 : A->pB1;
-  update_body(blockIdx.x, A->ctasks, A->cranges, A->L, j, A->pA, pBcur, pBnext, A->u1, A->Z, Rj, Rjm1, Rn, sm3);
-}
-
 // Number of eigenvalues of T_m (diag a[0..m), squared off-diagonals bb[1..m), both in LDS) that
 // are < x, by sign changes of the leading principal minors p_i = det(T_i - x I), rescaled by
 // powers of two.  The LDS reads do not depend on the recurrence, so they pipeline.
@@ -796,27 +743,6 @@ __global__ __launch_bounds__(64) void k_lz_bnew(const TaskRange* __restrict__ se
   nn = ai_wave_sum(nn);
   gg = ai_wave_sum(gg);
   if (threadIdx.x == 0) bnew_out[s] = sqrt(fmax(nn - gg * gg, 0.0));
-}
-
-// graph form: m = the device step counter after the batch; the output slot rotates with the batch number
-__global__ __launch_bounds__(64) void k_lz_bnew_g(const LzArgs* __restrict__ A) {
-  const int s = blockIdx.x;
-  if (s >= A->S) return;
-  if (A->mode[s] != 0 || A->L.frozen[s]) return;
-  const int mraw = A->step[0];
-  const int m = min(mraw, A->L.mcap);
-  const double2* pB = (m & 1) ? A->pB1 : A->pB0;
-  double* out = A->bnew + (size_t)((mraw / AI_GRAPH_STEPS) % AI_CHECK_DEPTH) * (A->S + 1);
-  const TaskRange rg = A->segrange[s];
-  double nn = 0.0, gg = 0.0;
-  for (int t = rg.z + threadIdx.x; t < rg.w; t += 64) {
-    const double2 v = pB[t];
-    nn += v.x;
-    gg += v.y;
-  }
-  nn = ai_wave_sum(nn);
-  gg = ai_wave_sum(gg);
-  if (threadIdx.x == 0) out[s] = sqrt(fmax(nn - gg * gg, 0.0));
 }
 
 // Convergence check after step j (m = j + 1 rows of T), one 256-thread block per running segment, on
@@ -1996,7 +1922,7 @@ class Solver {
     AI_TRY(pA.ensure(lzf.n + 1));
     AI_TRY(pB[0].ensure(lzc.n + 1));
     AI_TRY(pB[1].ensure(lzc.n + 1));
-    Pack pk(ctx->stage + AI_STAGE_BYTES / 4, AI_STAGE_BYTES / 4 - 16384);  // the tail holds the slab table and LzArgs
+    Pack pk(ctx->stage + AI_STAGE_BYTES / 4, AI_STAGE_BYTES / 4 - 16384);  // the tail holds the slab table
     pk.add(&s_mode.p, mode.data(), (size_t)S_ + 1);
     pk.add(&segrange.p, h_segrange.data(), (size_t)S_ + 1);
     pk.add(&lzf.d.p, lzf.h.data(), (size_t)lzf.n);
@@ -2177,70 +2103,7 @@ class Solver {
       }
       return AI_OK;
     };
-    hipGraphExec_t gexec = nullptr;
-    // opt-in: measured slower than plain launches on MI355X (replay floor + power-of-two grids), kept for experiments
-    bool use_graph = !dense_checks && !time_spmv && S_ <= 128 && getenv("AI_USE_GRAPH") != nullptr;
-    if (use_graph && lz_graph(lzf.n, lzc.n, &gexec) != AI_OK) use_graph = false;
-    if (use_graph) {
-      // level constants -> the device block the graph kernels read
-      LzArgs* ha = (LzArgs*)(ctx->stage + AI_STAGE_BYTES / 2 - 4096);
-      AI_TRY(sync_slabtab());
-      ha->ftasks = lzf.d.p;
-      ha->ctasks = lzc.d.p;
-      ha->cranges = cranges.p;
-      ha->segrange = segrange.p;
-      ha->mode = s_mode.p;
-      ha->rowptr = rowptr;
-      ha->col = col;
-      ha->wm = wm.p;
-      ha->sinv2 = sinv2.p;
-      ha->u1 = u1.p;
-      ha->Z = Y.p;
-      ha->pA = pA.p;
-      ha->pB0 = pB[0].p;
-      ha->pB1 = pB[1].p;
-      ha->slabs = d_slabtab.p;
-      ha->bnew = bnew_buf.p;
-      ha->step = ctx->lz_step_dev;
-      ha->stride = slab_stride;
-      ha->L = L;
-      ha->nft = lzf.n;
-      ha->nct = lzc.n;
-      ha->S = S_;
-      AI_HIP(hipMemcpyAsync(ctx->lz_args_dev, ha, sizeof(LzArgs), hipMemcpyHostToDevice, st));
-      AI_HIP(hipMemsetAsync(ctx->lz_step_dev, 0, 2 * sizeof(int32_t), st));
-      int launched = 0;
-      while (launched < mcap && !done) {
-        const int upto = std::min(launched + AI_GRAPH_STEPS, mcap);
-        for (int j = launched; j <= upto; ++j) AI_TRY(ensure_vec(j));
-        AI_TRY(sync_slabtab());
-        AI_HIP(hipGraphLaunch(gexec, st));
-        launched += AI_GRAPH_STEPS;
-        const int m = std::min(launched, mcap);
-        if (nchecks < AI_MAX_CHECKS) {
-          if (pending.size() - phead >= (size_t)AI_CHECK_DEPTH - 1) AI_TRY(reap(true));
-          const int cd = (launched / AI_GRAPH_STEPS) % AI_CHECK_DEPTH;  // the slot k_lz_bnew_g wrote
-          const double* bn = bnew_buf.p + (size_t)cd * (S_ + 1);
-          AI_HIP(hipEventRecord(ctx->chk_ev1[cd], st));
-          AI_HIP(hipStreamWaitEvent(ctx->side, ctx->chk_ev1[cd], 0));
-          const int with_rb = (size_t)3 * m * sizeof(double) <= (size_t)64 * 1024;
-          hipLaunchKernelGGL(k_lz_check, dim3(S_), dim3(AI_CHECK_THREADS), (size_t)(with_rb ? 3 : 2) * m * sizeof(double), ctx->side, seg_start.p, segrange.p,
-                             s_mode.p, L, bn, m, opt.tol, opt.max_iter, m - last_check_m, rowptr, s_theta.p, s_resid.p, slots.p + nchecks, work.p,
-                             with_rb);
-          AI_KERNEL_CHECK();
-          AI_HIP(hipMemcpyAsync(&ctx->pinned[nchecks % AI_PINNED_INTS], slots.p + nchecks, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->side));
-          AI_HIP(hipEventRecord(ctx->chk_ev[cd], ctx->side));
-          pending.push_back(Pending{nchecks, m, cd});
-          ++nchecks;
-          last_check_m = m;
-        }
-        // at most two batches past an unread check
-        const bool must = (phead < pending.size()) && (m - pending[phead].m >= 2 * AI_GRAPH_STEPS || m == mcap);
-        AI_TRY(reap(must));
-      }
-      steps = std::min(launched, mcap);
-    }
-    for (int j = 0; j < mcap && !done && !use_graph; ++j) {
+    for (int j = 0; j < mcap && !done; ++j) {
       AI_TRY(ensure_vec(j + 1));
       if (time_spmv) {
         while (evpool.size() < (size_t)2 * (j + 1)) {
@@ -2394,33 +2257,6 @@ class Solver {
     return AI_OK;
   }
 
-  // instantiated graph of AI_GRAPH_STEPS x (SpMV, update) + b_m, for a grid-size class
-  int lz_graph(int nft, int nct, hipGraphExec_t* out) {
-    int gf = 64;
-    while (gf < nft) gf <<= 1;
-    const int gc = gf / (AI_COARSE_ROWS / AI_FINE_ROWS) + 128;
-    if (nct > gc) return AI_ERR_INTERNAL;  // caller falls back to plain launches
-    for (auto& g : ctx->lz_graphs)
-      if (g.grid_f == gf && g.grid_c == gc) {
-        *out = g.exec;
-        return AI_OK;
-      }
-    const LzArgs* A = (const LzArgs*)ctx->lz_args_dev;
-    hipGraph_t graph;
-    AI_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    for (int u = 0; u < AI_GRAPH_STEPS; ++u) {
-      hipLaunchKernelGGL(k_lz_spmv_g, dim3(gf), dim3(AI_BLOCK), 0, st, A);
-      hipLaunchKernelGGL(k_lz_update_g, dim3(gc), dim3(AI_BLOCK), 0, st, A);
-    }
-    hipLaunchKernelGGL(k_lz_bnew_g, dim3(128), dim3(64), 0, st, A);
-    AI_HIP(hipStreamEndCapture(st, &graph));
-    hipGraphExec_t exec;
-    AI_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-    AI_HIP(hipGraphDestroy(graph));
-    ctx->lz_graphs.push_back(ai_ctx::GraphEntry{gf, gc, exec});
-    *out = exec;
-    return AI_OK;
-  }
 
   int lanczos_fro(int k1, std::vector<double>& thetas, std::vector<double>& resids, double* out, size_t out_stride, int* steps_out) {
     const int S_ = S();
