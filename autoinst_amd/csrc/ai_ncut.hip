@@ -383,6 +383,7 @@ __global__ __launch_bounds__(AI_BLOCK) void k_lz_spmv_t(const Task* __restrict__
 // gather becomes an LDS read.  Sums are formed in exactly the order of the plain kernel.
 #define AI_ENC_MAXNNZ 4096  // entries of a task the encoder sorts in LDS
 #define AI_ENC_XCAP 1024    // distinct columns of a task staged in LDS (8 KB)
+#define AI_SPMV_PF 4         // rounds of 16 entries per row whose loads are in flight before the barrier
 struct TaskEnc {
   int32_t uoff, ucnt;  // slice of the ucol pool; ucnt < 0: not encoded, the task gathers from global memory
 };
@@ -504,35 +505,33 @@ __global__ __launch_bounds__(AI_BLOCK) void k_lz_spmv_x(const Task* __restrict__
   }
 #pragma unroll
   for (int u = 0; u < ILP; ++u) len = max(len, p1[u] - p0[u]);
-  // the streamed loads of the first round do not depend on xs: issue them before the barrier
-  int c0[ILP];
-  double w0[ILP];
+  // the streamed loads do not depend on xs: the first AI_SPMV_PF rounds (48 entries of a row: most rows
+  // end there) are issued before the barrier, so that a block's dependent chain is
+  // task -> (distinct columns | row pointers) -> (R_j gather | entries) -> sums
+  constexpr int PF = AI_SPMV_PF;
+  int cq[PF][ILP];
+  double wq[PF][ILP];
 #pragma unroll
-  for (int u = 0; u < ILP; ++u) {
-    const int p = p0[u] + l;
-    const bool ok = p < p1[u];
-    c0[u] = ok ? (int)lidx[p] : -1;
-    w0[u] = ok ? wm[p] : 0.0;
-  }
-  __syncthreads();
-  for (int k = l; k < len; k += LPR) {
-    int c[ILP];
-    double w[ILP];
+  for (int q = 0; q < PF; ++q)
 #pragma unroll
     for (int u = 0; u < ILP; ++u) {
-      c[u] = c0[u];
-      w[u] = w0[u];
-    }
-#pragma unroll
-    for (int u = 0; u < ILP; ++u) {  // next round's entries are in flight while this round is summed
-      const int p = p0[u] + k + LPR;
+      const int p = p0[u] + l + q * LPR;
       const bool ok = p < p1[u];
-      c0[u] = ok ? (int)lidx[p] : -1;
-      w0[u] = ok ? wm[p] : 0.0;
+      cq[q][u] = ok ? (int)lidx[p] : -1;
+      wq[q][u] = ok ? wm[p] : 0.0;
     }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < PF; ++q)
 #pragma unroll
     for (int u = 0; u < ILP; ++u)
-      if (c[u] >= 0) sum[u] = fma(w[u], xs[c[u]], sum[u]);
+      if (cq[q][u] >= 0) sum[u] = fma(wq[q][u], xs[cq[q][u]], sum[u]);
+  for (int k = l + PF * LPR; k < len; k += LPR) {  // long rows: one more round at a time
+#pragma unroll
+    for (int u = 0; u < ILP; ++u) {
+      const int p = p0[u] + k;
+      if (p < p1[u]) sum[u] = fma(wm[p], xs[lidx[p]], sum[u]);
+    }
   }
   double acc = 0.0;
 #pragma unroll
