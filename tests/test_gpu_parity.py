@@ -286,3 +286,42 @@ def test_staged_gather_equals_plain_gather_bitwise(api, monkeypatch, n, spread):
         for k, grp in enumerate(exp):
             lab[grp] = k
         assert ncuts_ref.partitions_equal(l0, lab)
+
+
+def test_concurrent_contexts_give_the_sequential_results(api):
+    """bench.py's arrangement: several host threads, one Context each, batched calls in flight together
+    (the C calls release the GIL) -- every chunk's labels equal those of a plain sequential call."""
+    import threading
+    from autoinst_amd import synth
+    chunks = [synth.synthetic_chunk(n, seed, tarl=True) for n, seed in ((7000, 21), (12000, 22), (5000, 23), (9000, 24), (16000, 25), (6000, 26))]
+    ref = []
+    for c in chunks:
+        g = api.build_affinity(c["points"], c["tarl"], alpha=1.0, theta=0.5, gamma=0.0)
+        ref.append(api.ncuts_labels(g, g.n, 0.03)[0])
+        g.free()
+    out = [None] * 3
+    err = []
+
+    def work(k):
+        try:
+            ctx = api.Context(0)
+            for _ in range(3):   # repeated, so that the threads really overlap and buffers get re-used
+                graphs = [api.build_affinity(c["points"], c["tarl"], alpha=1.0, theta=0.5, gamma=0.0, ctx=ctx) for c in chunks[2 * k:2 * k + 2]]
+                labs, _, st = api.ncuts_labels_batch(graphs, None, 0.03)
+                for g in graphs:
+                    g.free()
+                assert st["unconverged"] == 0
+            out[k] = labs
+            ctx.close()
+        except BaseException as e:   # noqa: BLE001 - reported in the main thread
+            err.append(e)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not err, err
+    for k in range(3):
+        for b in range(2):
+            assert np.array_equal(out[k][b], ref[2 * k + b])
