@@ -2080,7 +2080,7 @@ class Solver {
     // an event and read a few steps later, so the stream never drains.  A finished segment's
     // blocks exit at their activity flag, so steps launched past the end cost next to nothing;
     // the host still never runs more than AI_RUNAHEAD steps past an unread check.
-    static const int AI_RUNAHEAD = getenv("AI_RUNAHEAD") ? atoi(getenv("AI_RUNAHEAD")) : 6;
+    static const int AI_RUNAHEAD = getenv("AI_RUNAHEAD") ? atoi(getenv("AI_RUNAHEAD")) : 10;
     struct Pending { int slot, m, ev; };
     std::vector<Pending> pending;  // FIFO of in-flight checks
     size_t phead = 0;
