@@ -328,16 +328,16 @@ def ncuts_chunk(dataset, chunk_downsample_dict, pcd_nonground_minor, T_pcd, samp
 
     Must be imported from inside the reference's ``pipeline/`` tree (it uses the reference's own
     ``utils`` / ``config`` modules and open3d for everything that is not the hot path: feature
-    pooling upstream, colour painting and 1-NN re-projection downstream).  Lines 60-174 of the
+    pooling upstream, colour painting and ground handling downstream).  Lines 60-174 of the
     reference -- the dense affinity matrices, ``remove_isolated_points`` and ``normalized_cut`` --
-    are replaced by `build_affinity` + `ncuts_labels`.
+    are replaced by `build_affinity` + `ncuts_labels`, and the 1-NN colour re-projection (:185-188) by
+    `points_api.nn1_reproject`.
     """
     import open3d as o3d  # noqa: F401  (reference dependency, not present in the build containers)
     import config as refcfg
     from utils.image.image_utils import dinov2_mean, image_based_features_per_patch
     from utils.point_cloud.chunk_generation import get_indices_feature_reprojection, tarl_features_per_patch
-    from utils.point_cloud.point_cloud_utils import (get_statistical_inlier_indices, get_subpcd,
-                                                     kDTree_1NN_feature_reprojection)
+    from utils.point_cloud.point_cloud_utils import get_statistical_inlier_indices, get_subpcd
     from utils.visualization_utils import generate_random_colors
 
     cfg = refcfg.CONFIG
@@ -384,7 +384,9 @@ def ncuts_chunk(dataset, chunk_downsample_dict, pcd_nonground_minor, T_pcd, samp
     for i, s in enumerate(grouped_labels):
         pcd_color[s] = np.array(random_colors[i]) / 255
     pcd_chunk.paint_uniform_color([0, 0, 0])
-    colors = kDTree_1NN_feature_reprojection(np.asarray(pcd_chunk.colors), pcd_chunk, pcd_color, chunk_major)
+    # kDTree_1NN_feature_reprojection (point_cloud_utils.py:144-174, a Python loop over the fine points) on the device
+    from .points_api import nn1_reproject
+    colors = nn1_reproject(np.asarray(pcd_chunk.colors), np.asarray(pcd_chunk.points), pcd_color, points_major)
     pcd_chunk.colors = o3d.utility.Vector3dVector(colors)
 
     inliers = get_statistical_inlier_indices(pcd_ground_chunk)
