@@ -34,6 +34,7 @@
 #define AI_COARSE_ROWS 512   // rows per block in the thread-per-row kernels (256 / 1024 measured within 2 %)
 #define AI_ROW_ILP (AI_FINE_ROWS / (AI_BLOCK / AI_LPR))
 #define AI_SLAB_VECS 32      // Lanczos vectors per HBM slab
+#define AI_ROW_PF 4         // rounds of 16 entries per row loaded together in the 16-lanes-per-row kernels
 #define AI_SWEEP_VALS 40     // per-task sweep partials: cut[10], assocA[10], assocB[10], cntA[10]
 #define AI_MAX_CHECKS 4096   // convergence checks per level (one counter slot each)
 
@@ -63,7 +64,19 @@ __global__ __launch_bounds__(AI_BLOCK) void k_degree(const Task* __restrict__ ta
   for (int row = tk.x + r; row < tk.y; row += AI_BLOCK / AI_LPR) {
     const int p0 = rowptr[row], p1 = rowptr[row + 1];
     double s = 0.0;
-    for (int p = p0 + l; p < p1; p += AI_LPR) s += wraw[p];
+    {
+      // the first AI_ROW_PF rounds of a row (64 entries: nearly every row) are loaded together, then added in order
+      double w[AI_ROW_PF];
+#pragma unroll
+      for (int q = 0; q < AI_ROW_PF; ++q) {
+        const int p = p0 + l + q * AI_LPR;
+        w[q] = (p < p1) ? wraw[p] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < AI_ROW_PF; ++q)
+        if (p0 + l + q * AI_LPR < p1) s += w[q];
+    }
+    for (int p = p0 + l + AI_ROW_PF * AI_LPR; p < p1; p += AI_LPR) s += wraw[p];
     s = ai_group16_sum(s);
     if (l == 0) {
       const double d = s + 1.0;
@@ -98,7 +111,23 @@ __global__ __launch_bounds__(AI_BLOCK) void k_scale(const Task* __restrict__ tas
   for (int row = tk.x + r; row < tk.y; row += AI_BLOCK / AI_LPR) {
     const int p0 = rowptr[row], p1 = rowptr[row + 1];
     const double si = sinv[row];
-    for (int p = p0 + l; p < p1; p += AI_LPR) wm[p] = (si * wraw[p]) * sinv[col[p]];
+    {
+      int c[AI_ROW_PF];
+      double w[AI_ROW_PF], sj[AI_ROW_PF];
+#pragma unroll
+      for (int q = 0; q < AI_ROW_PF; ++q) {
+        const int p = p0 + l + q * AI_LPR;
+        const bool ok = p < p1;
+        c[q] = ok ? col[p] : -1;
+        w[q] = ok ? wraw[p] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < AI_ROW_PF; ++q) sj[q] = (c[q] >= 0) ? sinv[c[q]] : 0.0;
+#pragma unroll
+      for (int q = 0; q < AI_ROW_PF; ++q)
+        if (c[q] >= 0) wm[p0 + l + q * AI_LPR] = (si * w[q]) * sj[q];
+    }
+    for (int p = p0 + l + AI_ROW_PF * AI_LPR; p < p1; p += AI_LPR) wm[p] = (si * wraw[p]) * sinv[col[p]];
     if (l == 0) {
       sinv2[row] = si * si;
       u1[row] = sqrt(deg[row] / v);
@@ -1169,7 +1198,26 @@ __global__ __launch_bounds__(AI_BLOCK) void k_sweep(const Task* __restrict__ fta
   for (int row = tk.x + r; row < tk.y; row += AI_BLOCK / AI_LPR) {
     const int bi = bin[row];
     const int p0 = rowptr[row], p1 = rowptr[row + 1];
-    for (int p = p0 + l; p < p1; p += AI_LPR) {
+    {
+      int c[AI_ROW_PF], bj[AI_ROW_PF];
+      double w[AI_ROW_PF];
+#pragma unroll
+      for (int q = 0; q < AI_ROW_PF; ++q) {
+        const int p = p0 + l + q * AI_LPR;
+        const bool ok = p < p1;
+        c[q] = ok ? col[p] : -1;
+        w[q] = ok ? wraw[p] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < AI_ROW_PF; ++q) bj[q] = (c[q] >= 0) ? (int)bin[c[q]] : 0;
+#pragma unroll
+      for (int q = 0; q < AI_ROW_PF; ++q)
+        if (c[q] >= 0) {
+#pragma unroll
+          for (int k = 0; k < AI_NUM_CUTS; ++k) cut[k] += (k >= bj[q] && k < bi) ? w[q] : 0.0;
+        }
+    }
+    for (int p = p0 + l + AI_ROW_PF * AI_LPR; p < p1; p += AI_LPR) {
       const int bj = bin[col[p]];
       const double w = wraw[p];
 #pragma unroll
@@ -1322,7 +1370,19 @@ __global__ __launch_bounds__(AI_BLOCK) void k_rebuild_count(const int32_t* __res
   if (dst < 0) return;
   const int f = flag[row];
   int c = 0;
-  for (int p = rowptr[row] + l; p < rowptr[row + 1]; p += AI_LPR) c += (flag[col[p]] == f) ? 1 : 0;
+  const int p0 = rowptr[row], p1 = rowptr[row + 1];
+  {
+    int cc[AI_ROW_PF];
+#pragma unroll
+    for (int q = 0; q < AI_ROW_PF; ++q) {
+      const int p = p0 + l + q * AI_LPR;
+      cc[q] = (p < p1) ? col[p] : -1;
+    }
+#pragma unroll
+    for (int q = 0; q < AI_ROW_PF; ++q)
+      if (cc[q] >= 0) c += (flag[cc[q]] == f) ? 1 : 0;
+  }
+  for (int p = p0 + l + AI_ROW_PF * AI_LPR; p < p1; p += AI_LPR) c += (flag[col[p]] == f) ? 1 : 0;
   c += __shfl_xor(c, 8, 16);
   c += __shfl_xor(c, 4, 16);
   c += __shfl_xor(c, 2, 16);
@@ -1347,7 +1407,35 @@ __global__ __launch_bounds__(AI_BLOCK) void k_rebuild_fill(const int32_t* __rest
   // all 64 lanes run the same number of rounds so that __ballot sees the whole wave
   int rounds = (p1 - p0 + AI_LPR - 1) / AI_LPR;
   for (int o = 32; o >= AI_LPR; o >>= 1) rounds = max(rounds, __shfl_xor(rounds, o, 64));
-  for (int it = 0; it < rounds; ++it) {
+  // the first AI_ROW_PF rounds: every load of the chain col -> (flag, map), and the weights, in flight together
+  int cq[AI_ROW_PF], mq[AI_ROW_PF];
+  bool kq[AI_ROW_PF];
+  double wq[AI_ROW_PF];
+#pragma unroll
+  for (int q = 0; q < AI_ROW_PF; ++q) {
+    const int p = p0 + q * AI_LPR + l;
+    const bool ok = p < p1;
+    cq[q] = ok ? col[p] : -1;
+    wq[q] = ok ? wraw[p] : 0.0;
+  }
+#pragma unroll
+  for (int q = 0; q < AI_ROW_PF; ++q) {
+    kq[q] = (cq[q] >= 0) && (flag[cq[q]] == f);
+    mq[q] = (cq[q] >= 0) ? map[cq[q]] : -1;
+  }
+#pragma unroll
+  for (int q = 0; q < AI_ROW_PF; ++q) {
+    if (q >= rounds) break;  // wave-uniform
+    const unsigned long long bal = __ballot(kq[q]);
+    const unsigned int gbits = (unsigned int)((bal >> (grp * AI_LPR)) & 0xffffull);
+    const int before = __popc(gbits & ((1u << l) - 1u));
+    if (kq[q]) {
+      new_col[out + before] = mq[q];
+      new_w[out + before] = wq[q];
+    }
+    out += __popc(gbits);
+  }
+  for (int it = AI_ROW_PF; it < rounds; ++it) {
     const int p = p0 + it * AI_LPR + l;
     int c = -1;
     bool keep = false;
