@@ -925,7 +925,8 @@ __global__ __launch_bounds__(AI_BLOCK) void k_ritz(const Task* __restrict__ ctas
   const double* cs = coef + (size_t)s * mcap + j0;
   for (int row = tk.x + threadIdx.x; row < tk.y; row += AI_BLOCK) {
     double acc = first ? cu[s] * u1[row] : ev[row];
-    for (int j = 0; j < jn; ++j) acc = fma(cs[j], slab[(size_t)j * stride + row], acc);
+#pragma unroll 8
+    for (int j = 0; j < jn; ++j) acc = fma(cs[j], slab[(size_t)j * stride + row], acc);  // same order, eight loads in flight
     ev[row] = acc;
   }
 }
