@@ -63,6 +63,22 @@ def test_200k_tarl_spatial_partition_properties(api, chunk200k):
     assert 0.0 <= s["S_assoc"] <= 1.0
 
 
+def test_200k_device_equals_model_exactly(api, chunk200k):
+    """BASELINE.json's full size: the HIP path and the NumPy model of the same algorithm (itself equal to
+    the imported reference on every fixture, tests/test_oracle.py) give identical groups in identical
+    order on the 200k-point TARL+Spatial chunk.  The graph is the device-built one, so this is the
+    recursion exactly as bench.py runs it."""
+    import gpu_model
+    ch = chunk200k
+    n = ch["points"].shape[0]
+    g = api.build_affinity(ch["points"], ch["tarl"], alpha=1.0, theta=0.5, gamma=0.0)
+    A = g.to_scipy()
+    g.free()
+    got = api.normalized_cut(A, n, np.arange(n), T=0.03)
+    exp = gpu_model.normalized_cut_model(A, n, np.arange(n), T=0.03)
+    assert len(got) == len(exp) and all(np.array_equal(a, b) for a, b in zip(got, exp))
+
+
 def test_50k_largest_component_eigen_residual(api):
     from autoinst_amd import synth
     pts, _ = synth.surface_chunk(50_000, seed=1)
