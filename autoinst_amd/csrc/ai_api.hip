@@ -46,6 +46,7 @@ void ai_arena::release_all() {
   cur = off = 0;
 }
 hipError_t ai_graph_cache::alloc(void** out, size_t bytes) {
+  std::lock_guard<std::mutex> lock(mu);
   bytes = (bytes + ((size_t)1 << 16) - 1) & ~(((size_t)1 << 16) - 1);
   // best fit among the kept buffers, at most 25 % (+1 MB) larger than asked for
   int best = -1;
@@ -76,6 +77,7 @@ hipError_t ai_graph_cache::alloc(void** out, size_t bytes) {
 
 void ai_graph_cache::release(void* p) {
   if (!p) return;
+  std::lock_guard<std::mutex> lock(mu);
   for (size_t i = 0; i < live.size(); ++i)
     if (live[i].p == p) {
       const Block b = live[i];
@@ -92,6 +94,7 @@ void ai_graph_cache::release(void* p) {
 }
 
 void ai_graph_cache::release_all() {
+  std::lock_guard<std::mutex> lock(mu);
   for (auto& b : free_list) (void)hipFree(b.p);
   for (auto& b : live) (void)hipFree(b.p);
   free_list.clear();

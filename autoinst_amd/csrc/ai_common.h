@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -72,6 +73,7 @@ struct ai_graph_cache {
     size_t cap;
   };
   std::vector<Block> free_list, live;
+  std::mutex mu;  // a graph may be released (e.g. by a garbage collector) on another thread than its context's
   size_t cached_bytes = 0;
   size_t max_cached_bytes = (size_t)32 << 30;
   hipError_t alloc(void** out, size_t bytes);
