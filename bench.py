@@ -16,7 +16,7 @@ Chunks are independent, so ranks process different chunks with no data-path coll
 ("weak" scaling: the same number of chunks per rank per step).
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the fused Lanczos SpMV,
-`k_lz_spmv`): algorithmic bytes of its launches / their summed duration, both from a profiled
+`k_lz_spmv_x`): algorithmic bytes of its launches / their summed duration, both from a profiled
 repeat of one batched call with HIP start/stop events on every dispatch (library's stream).
 `cpu_baseline` is the oracle (NumPy / SciPy restatement, scipy eigsh shift-invert as the
 reference) timed on this host on a bounded sample.
@@ -252,7 +252,7 @@ def main():
             "groups": int(ng),
             "unconverged": int(st["unconverged"]),
             "roofline": {
-                "kernel": "k_lz_spmv",
+                "kernel": "k_lz_spmv_x",
                 "bound": "hbm",
                 "achieved": ach,
                 "peak": HBM_PEAK_GBPS,
