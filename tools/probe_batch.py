@@ -1,5 +1,5 @@
 """Throughput of batched chunks on one GPU: python tools/probe_batch.py N K [threads]"""
-import sys, time, json, threading
+import os, sys, time, json, threading
 import numpy as np
 sys.path.insert(0, ".")
 import torch
@@ -15,7 +15,7 @@ ctxs = [api.Context(0) for _ in range(TH)]
 def work(t, reps):
     for _ in range(reps):
         graphs = [api.build_affinity(p, f, alpha=1.0, theta=0.5, gamma=0.0, ctx=ctxs[t]) for p, f in data[t * K:(t + 1) * K]]
-        labs, ngs, st = api.ncuts_labels_batch(graphs, None, 0.03)
+        labs, ngs, st = api.ncuts_labels_batch(graphs, None, 0.03, check_every=(int(os.environ["CE"]) if "CE" in os.environ else None))
         for g in graphs: g.free()
     return st
 def run(reps):
