@@ -393,3 +393,33 @@ def test_ncuts_chunk_drop_in_with_stand_in_pipeline_modules(api, monkeypatch):
     assert all(np.array_equal(chunk_out.colors[i], col_of[lab[nn[i]]]) for i in range(0, fine.shape[0], 97))
     assert merged.points.shape[0] == fine.shape[0] + cut.points.shape[0] and np.all(cut.colors == 0)
     assert inst_g.shape == seg_g.shape == (cut.points.shape[0],)
+
+
+def test_c_abi_rejects_bad_arguments(api):
+    """Status -1 (bad argument) surfaces as ValueError with the library's message, never as a crash."""
+    import ctypes as C
+    from autoinst_amd import _ffi, labels_api, points_api
+    lib = _ffi.load()
+    ctx = api.default_context()
+    pts = np.zeros((4, 3))
+    with pytest.raises(ValueError, match="radius"):
+        api.get_affinity_matrix(pts, alpha=1.0, theta=0.0, gamma=0.0, radius=0.0)
+    with pytest.raises(ValueError):
+        api.get_affinity_matrix(pts, np.zeros((4, 96)), alpha=1.0, theta=0.5, gamma=0.1)      # gamma without DINO
+    h = C.c_void_p()
+    assert lib.ai_affinity_build(ctx._h, None, 4, None, 0, None, 0, 1.0, 0.0, 0.0, 1.0, 0, C.byref(h)) == -1
+    assert b"ai_affinity_build" in lib.ai_last_error()
+    g = api.build_affinity(np.random.default_rng(0).normal(0, 1, (50, 3)), None, alpha=1.0, theta=0.0, gamma=0.0)
+    ng = C.c_int32()
+    assert lib.ai_ncut(ctx._h, g._h, 50, 0.1, 0.01, None, None, C.byref(ng), None) == -1          # labels_out missing
+    with pytest.raises(ValueError):
+        api.eigs_smallest(g, 0)
+    with pytest.raises(ValueError):
+        api.eigs_smallest(g, 65)
+    g.free()
+    with pytest.raises(ValueError):
+        labels_api.label_pairs(np.zeros(3, np.int32), np.zeros(4, np.int32))
+    with pytest.raises(ValueError):
+        labels_api.merge_associate(np.zeros((3, 3)), np.zeros(3, np.int32), np.zeros((2, 3)), np.zeros(2, np.int32), np.zeros(3), 0, 2)
+    with pytest.raises(ValueError):
+        points_api.tarl_pool(np.zeros((3, 3)), np.zeros((5, 3)), np.zeros((4, 96), np.float32))
