@@ -214,7 +214,8 @@ __global__ __launch_bounds__(AI_BLOCK) void k_weights(const int32_t* __restrict_
                                                       double* __restrict__ val, const int32_t* __restrict__ orig, int64_t n,
                                                       const double* __restrict__ tarl, int32_t tdim,
                                                       const uint8_t* __restrict__ notarl, const double* __restrict__ dino,
-                                                      int32_t ddim, double alpha, double theta, double gamma) {
+                                                      int32_t ddim, double alpha, double theta, double gamma,
+                                                      const int32_t* __restrict__ sam, int32_t nviews, double beta) {
   // workgroups are dealt round-robin to the 8 XCDs: remap so that each XCD walks one contiguous eighth of
   // the Morton-ordered rows and the neighbours' feature rows are re-used from ITS 4 MB L2 (the 154 MB
   // feature matrix itself only fits the Infinity Cache)
@@ -267,6 +268,20 @@ __global__ __launch_bounds__(AI_BLOCK) void k_weights(const int32_t* __restrict_
       double w = 1.0;
       if (use_t) w = exp(-theta * sqrt(my_t2));
       if (alpha != 0.0) w = w * exp(-alpha * d);
+      if (sam != nullptr && beta != 0.0) {
+        // SAM factor (utils/image/image_utils.py:64-89): fraction of the views in which both points carry an
+        // id (!= -1) and the ids differ
+        const int64_t oj = orig[col[e]];
+        int co = 0, diff = 0;
+        for (int v = 0; v < nviews; ++v) {
+          const int32_t a = sam[oi * nviews + v], b = sam[oj * nviews + v];
+          const bool both = (a != -1) && (b != -1);
+          co += both ? 1 : 0;
+          diff += (both && a != b) ? 1 : 0;
+        }
+        const double frac = co ? (double)diff / (double)co : 0.0;
+        w = w * exp(-beta * frac);
+      }
       if (use_d) w = w * exp(-gamma * sqrt(my_g2));
       val[e] = w;
     }
@@ -295,8 +310,19 @@ static int upload_if_host(const double* src, size_t count, int mem_kind, DevBuf<
 extern "C" int ai_affinity_build(ai_ctx* ctx, const double* xyz, int64_t n, const double* tarl, int32_t tarl_dim,
                                  const double* dino, int32_t dino_dim, double alpha, double theta, double gamma,
                                  double radius, int mem_kind, ai_csr** out) {
+  return ai_affinity_build_sam(ctx, xyz, n, tarl, tarl_dim, dino, dino_dim, nullptr, 0, alpha, 0.0, gamma, theta, radius, mem_kind, out);
+}
+
+extern "C" int ai_affinity_build_sam(ai_ctx* ctx, const double* xyz, int64_t n, const double* tarl, int32_t tarl_dim,
+                                     const double* dino, int32_t dino_dim, const int32_t* sam, int32_t sam_views, double alpha,
+                                     double beta, double gamma, double theta, double radius, int mem_kind, ai_csr** out) {
   if (!ctx || !xyz || !out || n <= 0 || !(radius > 0.0)) {
     ai_set_error("ai_affinity_build: bad argument (ctx/xyz/out null, n <= 0 or radius <= 0)");
+    return AI_ERR_BAD_ARG;
+  }
+  if (beta != 0.0 && (sam == nullptr || sam_views <= 0)) {
+    // ncuts_utils.py:116-117 raises ValueError("The length should be longer than 0!")
+    ai_set_error("ai_affinity_build: beta != 0 needs SAM ids (the reference raises ValueError here)");
     return AI_ERR_BAD_ARG;
   }
   if (n >= (int64_t)1 << 30) {
@@ -322,6 +348,17 @@ extern "C" int ai_affinity_build(ai_ctx* ctx, const double* xyz, int64_t n, cons
   AI_TRY(upload_if_host(xyz, (size_t)n * 3, mem_kind, own_xyz, &d_xyz, st));
   AI_TRY(upload_if_host(theta != 0.0 ? tarl : nullptr, (size_t)n * (size_t)(tarl_dim > 0 ? tarl_dim : 0), mem_kind, own_tarl, &d_tarl, st));
   AI_TRY(upload_if_host(gamma != 0.0 ? dino : nullptr, (size_t)n * (size_t)(dino_dim > 0 ? dino_dim : 0), mem_kind, own_dino, &d_dino, st));
+  DevBuf<int32_t> own_sam;
+  const int32_t* d_sam = nullptr;
+  if (beta != 0.0) {
+    if (mem_kind == AI_MEM_DEVICE) {
+      d_sam = sam;
+    } else {
+      AI_TRY(own_sam.alloc((size_t)n * sam_views));
+      AI_HIP(hipMemcpyAsync(own_sam.p, sam, (size_t)n * sam_views * sizeof(int32_t), hipMemcpyHostToDevice, st));
+      d_sam = own_sam.p;
+    }
+  }
 
   // bounds
   const int nb = 256;
@@ -455,7 +492,8 @@ extern "C" int ai_affinity_build(ai_ctx* ctx, const double* xyz, int64_t n, cons
     const bool t96 = d_tarl != nullptr && tarl_dim == 96, d384 = d_dino != nullptr && dino_dim == 384;
 #define AI_LAUNCH_W(TK, DK)                                                                                                          \
   hipLaunchKernelGGL((k_weights<TK, DK>), dim3(gw), dim3(AI_BLOCK), 0, st, (const int32_t*)A->rowptr, (const int32_t*)A->col, A->val, \
-                     (const int32_t*)A->orig, n, d_tarl, tarl_dim, (const uint8_t*)notarl.p, d_dino, dino_dim, alpha, theta, gamma)
+                     (const int32_t*)A->orig, n, d_tarl, tarl_dim, (const uint8_t*)notarl.p, d_dino, dino_dim, alpha, theta, gamma, d_sam, \
+                     sam_views, beta)
     if (t96 && d384)
       AI_LAUNCH_W(6, 24);
     else if (t96)

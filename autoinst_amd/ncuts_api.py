@@ -137,17 +137,22 @@ def _dev_f64(a, cols, name):
 
 
 def build_affinity(points, tarl=None, dino=None, *, alpha=CONFIG["alpha"], theta=CONFIG["theta"],
-                   gamma=CONFIG["gamma"], radius=PROXIMITY_THRESHOLD, ctx: Context | None = None) -> DeviceGraph:
+                   gamma=CONFIG["gamma"], radius=PROXIMITY_THRESHOLD, sam=None, beta=0.0,
+                   ctx: Context | None = None) -> DeviceGraph:
     """Affinity graph of one chunk, left on the device (``ncuts_utils.py:60-67,112-167``).
 
-    ``A_ij = 1[d_ij <= radius] * exp(-theta t_ij) * exp(-alpha d_ij) * exp(-gamma g_ij)`` with the
-    reference's rules: a falsy weight drops its factor, all-zero TARL rows have t = 0, A_ii = 1.
-    Inputs are NumPy arrays (copied to the device by the call) or torch tensors that already
-    live on the context's GPU (used in place; PyTorch here is only the owner of the HBM buffer).
+    ``A_ij = 1[d_ij <= radius] * exp(-theta t_ij) * exp(-alpha d_ij) * exp(-beta s_ij) * exp(-gamma g_ij)``
+    with the reference's rules: a falsy weight drops its factor, all-zero TARL rows have t = 0, A_ii = 1;
+    ``s_ij`` = fraction of the views in which both points carry a SAM id and the ids differ (``sam``:
+    (N, views) int ids of one camera, -1 = none; ``utils/image/image_utils.py:64-89``; beta is 0 in every
+    shipped config).  Inputs are NumPy arrays (copied to the device by the call) or torch tensors that
+    already live on the context's GPU (used in place; PyTorch here is only the owner of the HBM buffer).
     """
     ctx = ctx or default_context()
     if gamma and dino is None:
         raise ValueError("The length should be longer than 0!")  # ncuts_utils.py:126-127
+    if beta and sam is None:
+        raise ValueError("The length should be longer than 0!")  # ncuts_utils.py:116-117
     if theta and tarl is None:
         raise ValueError("theta != 0 needs TARL features")
     on_dev = _is_device_tensor(points)
@@ -159,6 +164,11 @@ def build_affinity(points, tarl=None, dino=None, *, alpha=CONFIG["alpha"], theta
         for f in (t, d):
             if f is not None and not _is_device_tensor(f):
                 raise ValueError("points are on the device, so features must be too")
+        sm = None
+        if beta:
+            if not _is_device_tensor(sam) or sam.dtype != torch.int32 or not sam.is_contiguous() or sam.dim() != 2:
+                raise ValueError("points are on the device, so sam must be a contiguous int32 (N, views) tensor there too")
+            sm = sam
         torch.cuda.current_stream(pts.device).synchronize()  # producers of the buffers have finished
         ptr = lambda a: C.c_void_p(a.data_ptr()) if a is not None else None
         mem = _ffi.AI_MEM_DEVICE
@@ -166,24 +176,31 @@ def build_affinity(points, tarl=None, dino=None, *, alpha=CONFIG["alpha"], theta
         pts = _as_f64(points, 3, "points")
         t = _as_f64(tarl, None, "tarl") if theta else None
         d = _as_f64(dino, None, "dino") if gamma else None
+        sm = None
+        if beta:
+            sm = np.ascontiguousarray(np.asarray(sam), dtype=np.int32)
+            if sm.ndim != 2:
+                raise ValueError("sam must be (N, views)")
         ptr = lambda a: a.ctypes.data if a is not None else None
         mem = _ffi.AI_MEM_HOST
     n = pts.shape[0]
-    for f, nm in ((t, "tarl"), (d, "dino")):
+    for f, nm in ((t, "tarl"), (d, "dino"), (sm, "sam")):
         if f is not None and f.shape[0] != n:
             raise ValueError(f"{nm} has {f.shape[0]} rows for {n} points")
     h = C.c_void_p()
-    st = _ffi.load().ai_affinity_build(
+    st = _ffi.load().ai_affinity_build_sam(
         ctx._h, ptr(pts), n, ptr(t), t.shape[1] if t is not None else 0, ptr(d), d.shape[1] if d is not None else 0,
-        float(alpha or 0.0), float(theta or 0.0), float(gamma or 0.0), float(radius), mem, C.byref(h))
+        ptr(sm), sm.shape[1] if sm is not None else 0, float(alpha or 0.0), float(beta or 0.0), float(gamma or 0.0),
+        float(theta or 0.0), float(radius), mem, C.byref(h))
     _ffi.check(st, "ai_affinity_build")
     return DeviceGraph(ctx, h)
 
 
 def get_affinity_matrix(points, tarl=None, dino=None, *, alpha=CONFIG["alpha"], theta=CONFIG["theta"],
-                        gamma=CONFIG["gamma"], radius=PROXIMITY_THRESHOLD, ctx: Context | None = None) -> sp.csr_matrix:
+                        gamma=CONFIG["gamma"], radius=PROXIMITY_THRESHOLD, sam=None, beta=0.0,
+                        ctx: Context | None = None) -> sp.csr_matrix:
     """The CSR matrix the reference hands to ``normalized_cut`` (``ncuts_utils.py:167``)."""
-    g = build_affinity(points, tarl, dino, alpha=alpha, theta=theta, gamma=gamma, radius=radius, ctx=ctx)
+    g = build_affinity(points, tarl, dino, alpha=alpha, theta=theta, gamma=gamma, radius=radius, sam=sam, beta=beta, ctx=ctx)
     try:
         return g.to_scipy()
     finally:
@@ -263,10 +280,10 @@ def normalized_cut(w, num_points_orig, labels, T=0.01, split_lim=0.01, *, ctx: C
 
 
 def ncuts(points, tarl=None, dino=None, *, alpha=CONFIG["alpha"], theta=CONFIG["theta"], gamma=CONFIG["gamma"],
-          T=CONFIG["T"], split_lim=SPLIT_LIM, radius=PROXIMITY_THRESHOLD, ctx: Context | None = None,
-          tol=None, max_iter=None):
+          T=CONFIG["T"], split_lim=SPLIT_LIM, radius=PROXIMITY_THRESHOLD, sam=None, beta=0.0,
+          ctx: Context | None = None, tol=None, max_iter=None):
     """Array-level ``ncuts_chunk`` lines 60-174: points (+features) -> list of index arrays."""
-    g = build_affinity(points, tarl, dino, alpha=alpha, theta=theta, gamma=gamma, radius=radius, ctx=ctx)
+    g = build_affinity(points, tarl, dino, alpha=alpha, theta=theta, gamma=gamma, radius=radius, sam=sam, beta=beta, ctx=ctx)
     try:
         lab, ng, _ = ncuts_labels(g, g.n, T, split_lim, tol=tol, max_iter=max_iter)
     finally:
@@ -355,12 +372,25 @@ def ncuts_chunk(dataset, chunk_downsample_dict, pcd_nonground_minor, T_pcd, samp
     points_major = np.asarray(chunk_major.points)
     num_points_major = points_major.shape[0]
 
-    if cfg["beta"]:
-        raise NotImplementedError("SAM factor (beta != 0) is not exercised by any shipped config (config.py:12,23,34,45)")
-    dino = None
-    if cfg["gamma"]:
+    dino = sam = None
+    sam_list, point2dino_list = [], []
+    # the three call forms of ncuts_utils.py:69-110 (their return shapes differ)
+    if cfg["beta"] and not cfg["gamma"]:
+        sam_list = image_based_features_per_patch(dataset, pcd_nonground_minor, chunk_indices, chunk_major, T_pcd, cam_indices_global,
+                                                  sam=True, dino=False)
+    elif cfg["gamma"] and not cfg["beta"]:
         point2dino_list, _ = image_based_features_per_patch(dataset, pcd_nonground_minor, chunk_indices, chunk_major, T_pcd,
                                                             cam_indices_global, sam=False, dino=True, pcd_chunk=pcd_chunk)
+    elif cfg["beta"] and cfg["gamma"]:
+        sam_list, point2dino_list = image_based_features_per_patch(dataset, pcd_nonground_minor, chunk_indices, chunk_major, T_pcd,
+                                                                   cam_indices_global, sam=True, dino=True)
+    if cfg["beta"]:
+        if len(sam_list) == 0:
+            raise ValueError("The length should be longer than 0!")
+        if len(sam_list) != 1:
+            raise NotImplementedError("more than one camera (CAM_IDS has one entry, config.py:72)")
+        sam = np.asarray(sam_list[0])
+    if cfg["gamma"]:
         feats = [dinov2_mean(p2d) for p2d in point2dino_list]
         if len(feats) == 0:
             raise ValueError("The length should be longer than 0!")
@@ -372,7 +402,7 @@ def ncuts_chunk(dataset, chunk_downsample_dict, pcd_nonground_minor, T_pcd, samp
         tarl = np.asarray(tarl_features_per_patch(dataset, chunk_major, T_pcd, center_position, tarl_indices_global))
 
     graph = build_affinity(points_major, tarl, dino, alpha=cfg["alpha"], theta=cfg["theta"], gamma=cfg["gamma"],
-                           radius=refcfg.PROXIMITY_THRESHOLD)
+                           radius=refcfg.PROXIMITY_THRESHOLD, sam=sam, beta=cfg["beta"])
     try:
         lab, ng, _ = ncuts_labels(graph, num_points_major, cfg["T"], refcfg.SPLIT_LIM)
     finally:

@@ -65,6 +65,18 @@ int ai_affinity_build(ai_ctx* ctx, const double* xyz, int64_t n,
                       int mem_kind, ai_csr** out);
 
 /*
+ * The same with the SAM factor of ncuts_utils.py:112-123 / utils/image/image_utils.py:64-89 (beta is 0.0 in
+ * every shipped config, config.py:12,23,34,45, so the reference pipeline never takes this path): sam =
+ * (n, sam_views) int32 SAM ids of one camera, -1 = no id in that view; per pair inside the radius the
+ * factor is exp(-beta * fraction of the co-labelled views whose ids differ).  Factors are multiplied in
+ * the reference's order tarl * spatial * sam * dino (:151-156).  beta != 0 without ids is a bad argument
+ * (the reference raises ValueError, :116-117).
+ */
+int ai_affinity_build_sam(ai_ctx* ctx, const double* xyz, int64_t n, const double* tarl, int32_t tarl_dim,
+                          const double* dino, int32_t dino_dim, const int32_t* sam, int32_t sam_views, double alpha,
+                          double beta, double gamma, double theta, double radius, int mem_kind, ai_csr** out);
+
+/*
  * Upload a caller-built symmetric CSR (what ncuts_utils.py:167 hands to
  * normalized_cut at :168).  indptr has n+1 entries.  Row order is kept.
  */

@@ -31,11 +31,33 @@ NUM_CUTS = 10  # normalized_cut.py:54
 
 
 # --------------------------------------------------------------------------- affinity
-def affinity_dense(points, tarl=None, dino=None, *, alpha=1.0, theta=0.0, gamma=0.0, radius=1.0):
-    """Literal dense restatement of ``ncuts_utils.py:60-67, 112-156`` (beta = 0).
+def sam_label_distance(sam_features, spatial_distance, proximity_threshold, beta):
+    """``utils/image/image_utils.py:64-89`` literally: per pair inside the radius, the fraction of the
+    views in which both points carry a SAM id (!= -1) and the ids differ; weight exp(-beta * fraction)."""
+    mask = np.where(spatial_distance <= proximity_threshold)
+    num_points, num_views = sam_features.shape
+    distance_matrix = np.zeros((num_points, num_points))
+    for (point1, point2) in zip(*mask):
+        view_counter = 0
+        for view in range(num_views):
+            instance_id1 = sam_features[point1, view]
+            instance_id2 = sam_features[point2, view]
+            if instance_id1 != -1 and instance_id2 != -1:
+                view_counter += 1
+                if instance_id1 != instance_id2:
+                    distance_matrix[point1, point2] += 1
+        if view_counter:
+            distance_matrix[point1, point2] /= view_counter
+    mask = np.where(spatial_distance <= proximity_threshold, 1, 0)
+    return mask * np.exp(-beta * distance_matrix), mask
 
-    Returns the dense (N,N) float64 matrix A = tarl_w * spatial_w * sam_w * dino_w.
-    Only for small N (O(N^2) memory, like the reference).
+
+def affinity_dense(points, tarl=None, dino=None, *, alpha=1.0, theta=0.0, gamma=0.0, radius=1.0, sam=None, beta=0.0):
+    """Literal dense restatement of ``ncuts_utils.py:60-67, 112-156``.
+
+    Returns the dense (N,N) float64 matrix A = tarl_w * spatial_w * sam_w * dino_w.  ``sam`` is the
+    per-camera list of (N, views) SAM id matrices (or one such matrix).  Only for small N (O(N^2)
+    memory, like the reference).
     """
     points = np.asarray(points, dtype=np.float64)
     spatial_distance = cdist(points, points)                        # :60
@@ -44,8 +66,15 @@ def affinity_dense(points, tarl=None, dino=None, *, alpha=1.0, theta=0.0, gamma=
         spatial_w = mask * np.exp(-alpha * spatial_distance)
     else:
         spatial_w = mask
-    sam_w = mask.copy()                                             # :112 (beta == 0 in every shipped config)
+    sam_w = mask.copy()                                             # :112
     dino_w = mask.copy()                                            # :113
+    if beta:                                                        # :115-123
+        sam_list = [] if sam is None else (list(sam) if isinstance(sam, (list, tuple)) else [sam])
+        if len(sam_list) == 0:
+            raise ValueError("The length should be longer than 0!")  # :116-117
+        for sam_features_major in sam_list:
+            cam_w, _ = sam_label_distance(np.asarray(sam_features_major), spatial_distance, radius, beta)
+            sam_w = sam_w * cam_w
     if gamma:                                                       # :125-133
         if dino is None:
             raise ValueError("The length should be longer than 0!")  # :126-127
@@ -73,7 +102,7 @@ def remove_isolated_points(A):
     return keep, A[keep][:, keep]
 
 
-def affinity_sparse(points, tarl=None, dino=None, *, alpha=1.0, theta=0.0, gamma=0.0, radius=1.0):
+def affinity_sparse(points, tarl=None, dino=None, *, alpha=1.0, theta=0.0, gamma=0.0, radius=1.0, sam=None, beta=0.0):
     """Sparse restatement: same values as `affinity_dense` on the radius graph.
 
     CSR float64, int32 indices sorted per row, diagonal 1 stored -- i.e. exactly
@@ -101,6 +130,19 @@ def affinity_sparse(points, tarl=None, dino=None, *, alpha=1.0, theta=0.0, gamma
         t[no_tarl[i] | no_tarl[j]] = 0.0
         w = w * np.exp(-theta * t)
     w = w * spatial_w
+    if beta:
+        sam_list = [] if sam is None else (list(sam) if isinstance(sam, (list, tuple)) else [sam])
+        if len(sam_list) == 0:
+            raise ValueError("The length should be longer than 0!")
+        sam_w = np.ones_like(d)
+        for sf in sam_list:
+            sf = np.asarray(sf)
+            both = (sf[i] != -1) & (sf[j] != -1)
+            co = both.sum(1)
+            diff = (both & (sf[i] != sf[j])).sum(1).astype(np.float64)
+            frac = np.divide(diff, co, out=np.zeros_like(diff), where=co > 0)
+            sam_w = sam_w * np.exp(-beta * frac)
+        w = w * sam_w
     if gamma:
         if dino is None:
             raise ValueError("The length should be longer than 0!")

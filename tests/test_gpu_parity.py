@@ -423,3 +423,27 @@ def test_c_abi_rejects_bad_arguments(api):
         labels_api.merge_associate(np.zeros((3, 3)), np.zeros(3, np.int32), np.zeros((2, 3)), np.zeros(2, np.int32), np.zeros(3), 0, 2)
     with pytest.raises(ValueError):
         points_api.tarl_pool(np.zeros((3, 3)), np.zeros((5, 3)), np.zeros((4, 96), np.float32))
+
+
+def test_sam_factor_matches_oracle(api):
+    """Row a5: exp(-beta * fraction of co-labelled views with differing SAM ids), multiplied between the
+    spatial and the DINO factor (ncuts_utils.py:151-156)."""
+    rng = np.random.default_rng(12)
+    n = 4000
+    pts = rng.normal(0, 3.0, (n, 3))
+    tarl = rng.normal(0, 1, (n, 96))
+    tarl[::13] = 0.0
+    dino = rng.normal(0, 1, (n, 384))
+    sam = rng.integers(0, 5, (n, 6))
+    sam[rng.random((n, 6)) < 0.35] = -1
+    for kw in (dict(alpha=1.0, theta=0.5, gamma=0.0, beta=0.7), dict(alpha=1.0, theta=0.5, gamma=0.1, beta=1.3),
+               dict(alpha=0.0, theta=0.0, gamma=0.0, beta=2.0)):
+        A = api.get_affinity_matrix(pts, tarl, dino, sam=sam, **kw)
+        B = ncuts_ref.affinity_sparse(pts, tarl, dino, sam=sam, **kw)
+        assert np.array_equal(A.indptr, B.indptr) and np.array_equal(A.indices, B.indices)
+        assert (np.abs(A.data - B.data) / B.data).max() <= 1e-12
+        assert abs(A - A.T).max() == 0.0 and np.all(A.diagonal() == 1.0)
+    with pytest.raises(ValueError):
+        api.get_affinity_matrix(pts, tarl, None, alpha=1.0, theta=0.5, gamma=0.0, beta=0.5)
+    groups = api.ncuts(pts, tarl, None, sam=sam, alpha=1.0, theta=0.5, gamma=0.0, beta=0.7, T=0.03)
+    assert sorted(np.concatenate(groups).tolist()) == list(range(n))

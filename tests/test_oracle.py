@@ -147,3 +147,30 @@ def test_only_the_null_space_separates_oracle_and_device_algorithm(n):
     gh = hybrid(A, np.arange(n))
     gm = gpu_model.normalized_cut_model(A, n, np.arange(n), T=T)
     assert len(gh) == len(gm) and all(np.array_equal(a, b) for a, b in zip(gh, gm))
+
+
+def _sam_ids(n, views, seed):
+    rng = np.random.default_rng(seed)
+    ids = rng.integers(0, 4, (n, views))
+    ids[rng.random((n, views)) < 0.3] = -1      # no SAM id in that view
+    return ids
+
+
+def test_sam_factor_sparse_equals_literal_dense():
+    """Row a5 (beta != 0, never taken by the shipped configs): the sparse restatement of the SAM factor
+    equals the literal double loop of image_utils.py:64-89 inside the reference's product order."""
+    rng = np.random.default_rng(4)
+    pts = rng.normal(0, 1.2, (160, 3))
+    tarl = rng.normal(0, 1, (160, 96))
+    tarl[::11] = 0.0
+    sam = _sam_ids(160, 5, 9)
+    kw = dict(alpha=1.0, theta=0.5, gamma=0.0, beta=0.7)
+    D = ncuts_ref.affinity_dense(pts, tarl, None, sam=[sam], **kw)
+    A = ncuts_ref.affinity_sparse(pts, tarl, None, sam=sam, **kw)
+    assert np.array_equal(A.toarray() != 0, D != 0)
+    assert np.abs(A.toarray() - D).max() <= 1e-15
+    # the factor really acts: some pairs have differing ids in co-labelled views
+    B = ncuts_ref.affinity_sparse(pts, tarl, None, alpha=1.0, theta=0.5, gamma=0.0)
+    assert (A.data < B.data - 1e-6).any() and np.all(A.data <= B.data + 1e-15)
+    with pytest.raises(ValueError):
+        ncuts_ref.affinity_sparse(pts, tarl, None, alpha=1.0, theta=0.5, gamma=0.0, beta=0.7)
