@@ -327,7 +327,8 @@ def test_concurrent_contexts_give_the_sequential_results(api):
             assert np.array_equal(out[k][b], ref[2 * k + b])
 
 
-def test_ncuts_chunk_drop_in_with_stand_in_pipeline_modules(api, monkeypatch):
+@pytest.mark.parametrize("beta,gamma", [(0.0, 0.0), (0.7, 0.0), (0.0, 0.1), (0.7, 0.1)])
+def test_ncuts_chunk_drop_in_with_stand_in_pipeline_modules(api, monkeypatch, beta, gamma):
     """`ncuts_chunk` has the reference's signature and 5-tuple (ncuts_utils.py:28-204).  The reference's
     surroundings (open3d, its `config` and `utils` packages) are not importable here, so minimal
     stand-ins with the same names are injected for this test only: what is checked is the glue around
@@ -354,17 +355,29 @@ def test_ncuts_chunk_drop_in_with_stand_in_pipeline_modules(api, monkeypatch):
         monkeypatch.setitem(sys.modules, name, m)
         return m
 
-    ch = synth.synthetic_chunk(6000, 31, tarl=True)
+    ch = synth.synthetic_chunk(6000, 31, tarl=True, dino=True)
     rng = np.random.default_rng(0)
+    sam_ids = rng.integers(0, 4, (6000, 5))
+    sam_ids[rng.random((6000, 5)) < 0.3] = -1
+
+    def image_features(dataset, pcd, chunk_indices, chunk_nc, T_pcd, cam_idx, sam=False, dino=False, pcd_chunk=None):
+        # the three return shapes of utils/image/image_utils.py's image_based_features_per_patch
+        calls["image"] = (sam, dino, pcd_chunk is not None)
+        if sam and not dino:
+            return [sam_ids]
+        if dino and not sam:
+            return [ch["dino"]], None
+        return [sam_ids], [ch["dino"]]
+
     fine = np.concatenate([ch["points"] + rng.normal(0, 0.03, ch["points"].shape) for _ in range(2)])
     ground = np.stack([rng.uniform(-10, 10, 400), rng.uniform(-10, 10, 400), rng.normal(-1.5, 0.02, 400)], 1)
     calls = {}
     mod("open3d", utility=types.SimpleNamespace(Vector3dVector=lambda a: np.asarray(a)))
-    mod("config", CONFIG=dict(alpha=1.0, beta=0.0, gamma=0.0, theta=0.5, T=0.03), PROXIMITY_THRESHOLD=1.0, SPLIT_LIM=0.01,
+    mod("config", CONFIG=dict(alpha=1.0, beta=beta, gamma=gamma, theta=0.5, T=0.03), PROXIMITY_THRESHOLD=1.0, SPLIT_LIM=0.01,
         ADJACENT_FRAMES_CAM=(16, 13), ADJACENT_FRAMES_TARL=(10, 10), MEAN_HEIGHT=0.6)
     mod("utils")
     mod("utils.image")
-    mod("utils.image.image_utils", dinov2_mean=None, image_based_features_per_patch=None)
+    mod("utils.image.image_utils", dinov2_mean=lambda p2d: p2d, image_based_features_per_patch=image_features)
     mod("utils.point_cloud")
     mod("utils.point_cloud.chunk_generation",
         get_indices_feature_reprojection=lambda idx, first, adjacent_frames: (list(idx[:3]), None),
@@ -381,8 +394,10 @@ def test_ncuts_chunk_drop_in_with_stand_in_pipeline_modules(api, monkeypatch):
          "kitti_labels": {"ground": {"instance": [np.arange(400)], "semantic": [np.full(400, 40)]}}}
     merged, chunk_out, cut, inst_g, seg_g = api.ncuts_chunk(None, d, None, np.eye(4), list(range(20)), sequence=0, patchwise_indices=[[3, 4]])
     assert "tarl" in calls and chunk_out is pcd_chunk
+    assert calls.get("image") == ((bool(beta), bool(gamma), bool(gamma) and not beta) if (beta or gamma) else None)
     # the fine cloud carries the colour of the nearest major-voxel point; groups are painted with distinct colours
-    groups = api.ncuts(ch["points"], ch["tarl"], alpha=1.0, theta=0.5, gamma=0.0, T=0.03)
+    groups = api.ncuts(ch["points"], ch["tarl"], ch["dino"] if gamma else None, sam=sam_ids if beta else None, alpha=1.0, theta=0.5,
+                       gamma=gamma, beta=beta, T=0.03)
     assert np.unique(chunk_out.colors, axis=0).shape[0] == len(groups)
     from scipy.spatial import cKDTree
     nn = cKDTree(ch["points"]).query(fine)[1]
