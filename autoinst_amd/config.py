@@ -9,6 +9,8 @@ from __future__ import annotations
 PROXIMITY_THRESHOLD = 1.0   # config.py:65  radius of the affinity graph (metres, inclusive <=)
 SPLIT_LIM = 0.01            # config.py:61  segments <= 1 % of the original chunk are never split
 MAJOR_VOXEL_SIZE = 0.35     # config.py:56
+CHUNK_SIZE = (25.0, 25.0, 25.0)  # config.py:57 (metres)
+TARL_NORM = False           # config.py:64
 NUM_DINO_FEATURES = 384     # config.py:67
 NUM_TARL_FEATURES = 96      # tarl_extractor.py:84-89 (96-d MinkUNet features)
 NUM_CUTS = 10               # normalized_cut.py:54  get_min_ncut(ev, D, w, 10)

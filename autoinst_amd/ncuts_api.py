@@ -347,14 +347,15 @@ def ncuts_chunk(dataset, chunk_downsample_dict, pcd_nonground_minor, T_pcd, samp
     ``utils`` / ``config`` modules and open3d for everything that is not the hot path: feature
     pooling upstream, colour painting and ground handling downstream).  Lines 60-174 of the
     reference -- the dense affinity matrices, ``remove_isolated_points`` and ``normalized_cut`` --
-    are replaced by `build_affinity` + `ncuts_labels`, and the 1-NN colour re-projection (:185-188) by
-    `points_api.nn1_reproject`.
+    are replaced by `build_affinity` + `ncuts_labels`, the TARL radius-mean pooling (:136-142 ->
+    chunk_generation.py:243-256) by `points_api.tarl_features_per_patch`, and the 1-NN colour
+    re-projection (:185-188) by `points_api.nn1_reproject`.
     """
     import open3d as o3d  # noqa: F401  (reference dependency, not present in the build containers)
     import config as refcfg
     from utils.image.image_utils import dinov2_mean, image_based_features_per_patch
-    from utils.point_cloud.chunk_generation import get_indices_feature_reprojection, tarl_features_per_patch
-    from utils.point_cloud.point_cloud_utils import get_statistical_inlier_indices, get_subpcd
+    from utils.point_cloud.chunk_generation import get_indices_feature_reprojection
+    from utils.point_cloud.point_cloud_utils import get_statistical_inlier_indices, get_subpcd, transform_pcd
     from utils.visualization_utils import generate_random_colors
 
     cfg = refcfg.CONFIG
@@ -399,7 +400,11 @@ def ncuts_chunk(dataset, chunk_downsample_dict, pcd_nonground_minor, T_pcd, samp
         dino = feats[0]
     tarl = None
     if cfg["theta"]:
-        tarl = np.asarray(tarl_features_per_patch(dataset, chunk_major, T_pcd, center_position, tarl_indices_global))
+        # tarl_features_per_patch (chunk_generation.py:205-258): its per-point radius search and mean run on the device
+        from .points_api import tarl_features_per_patch
+        tarl = tarl_features_per_patch(dataset, chunk_major, T_pcd, center_position, tarl_indices_global,
+                                       chunk_size=refcfg.CHUNK_SIZE, major_voxel_size=refcfg.MAJOR_VOXEL_SIZE,
+                                       tarl_norm=refcfg.TARL_NORM, transform_pcd=transform_pcd)
 
     graph = build_affinity(points_major, tarl, dino, alpha=cfg["alpha"], theta=cfg["theta"], gamma=cfg["gamma"],
                            radius=refcfg.PROXIMITY_THRESHOLD, sam=sam, beta=cfg["beta"])

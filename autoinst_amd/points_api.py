@@ -13,7 +13,7 @@ import ctypes as C
 import numpy as np
 
 from . import _ffi
-from .config import MAJOR_VOXEL_SIZE
+from .config import CHUNK_SIZE, MAJOR_VOXEL_SIZE, TARL_NORM
 from .ncuts_api import Context, default_context
 
 
@@ -37,6 +37,50 @@ def tarl_pool(points_major, tarl_points, tarl_features, *, radius=MAJOR_VOXEL_SI
     _ffi.check(_ffi.load().ai_radius_mean_pool(ctx._h, q.ctypes.data, q.shape[0], s.ctypes.data, s.shape[0], f.ctypes.data,
                                                f.shape[1], float(radius), _ffi.AI_MEM_HOST, out.ctypes.data, cnt.ctypes.data),
                "ai_radius_mean_pool")
+    return out
+
+
+def _transform_points(points, T):
+    """open3d ``PointCloud.transform``: homogeneous 4x4 applied to every point, divided by w."""
+    p = np.asarray(points, dtype=np.float64)
+    T = np.asarray(T, dtype=np.float64)
+    q = p @ T[:3, :3].T + T[:3, 3]
+    w = p @ T[3, :3] + T[3, 3]
+    return q / w[:, None]
+
+
+def tarl_features_per_patch(dataset, pcd, T_pcd, center_position, tarl_indices, *, chunk_size=CHUNK_SIZE,
+                            major_voxel_size=MAJOR_VOXEL_SIZE, tarl_norm=TARL_NORM, transform_pcd=None,
+                            ctx: Context | None = None):
+    """Drop-in for ``tarl_features_per_patch`` (``chunk_generation.py:205-258``, same five positional
+    arguments): the scan loop (:222-241, dataset reads, pose transform, crop to the chunk box) stays
+    on the host, the per-point radius search and mean (:243-256) run on the device.  ``dataset`` needs
+    ``get_tarl_features`` / ``get_point_cloud`` / ``get_pose`` like the reference's; ``pcd`` needs
+    ``.points``.  ``transform_pcd`` may be the reference's own function (open3d); the default applies
+    the same homogeneous transform in NumPy.
+    """
+    tf = transform_pcd or _transform_points
+    center_position = np.asarray(center_position, dtype=np.float64)
+    max_position = center_position + 0.5 * np.asarray(chunk_size, dtype=np.float64)            # :219-220
+    min_position = center_position - 0.5 * np.asarray(chunk_size, dtype=np.float64)
+    pts_list, feat_list = [], []
+    for points_index in tarl_indices:                                                            # :222
+        tarl_features = np.asarray(dataset.get_tarl_features(points_index))
+        coords = np.asarray(dataset.get_point_cloud(points_index))
+        T_local2global = np.linalg.inv(T_pcd) @ dataset.get_pose(points_index)                   # :229-231
+        coords = np.asarray(tf(coords, T_local2global))
+        mask = np.where(np.all(coords > min_position, axis=1) & np.all(coords < max_position, axis=1))[0]   # :233-236
+        pts_list.append(coords[mask])
+        feat_list.append(np.asarray(tarl_features[mask], dtype=np.float32))
+    points_major = np.asarray(pcd.points)
+    if not pts_list:
+        return np.zeros((points_major.shape[0], 96))                                              # :246 with no scan at all
+    out = tarl_pool(points_major, np.concatenate(pts_list), np.concatenate(feat_list),
+                    radius=major_voxel_size / 2.0, ctx=ctx)                                       # :243-252
+    if tarl_norm:                                                                                # :253-254
+        nrm = np.linalg.norm(out, axis=1)
+        has = out.any(axis=1)
+        out[has] /= nrm[has, None]
     return out
 
 

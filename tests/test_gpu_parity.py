@@ -374,17 +374,48 @@ def test_ncuts_chunk_drop_in_with_stand_in_pipeline_modules(api, monkeypatch, be
     calls = {}
     mod("open3d", utility=types.SimpleNamespace(Vector3dVector=lambda a: np.asarray(a)))
     mod("config", CONFIG=dict(alpha=1.0, beta=beta, gamma=gamma, theta=0.5, T=0.03), PROXIMITY_THRESHOLD=1.0, SPLIT_LIM=0.01,
-        ADJACENT_FRAMES_CAM=(16, 13), ADJACENT_FRAMES_TARL=(10, 10), MEAN_HEIGHT=0.6)
+        ADJACENT_FRAMES_CAM=(16, 13), ADJACENT_FRAMES_TARL=(10, 10), MEAN_HEIGHT=0.6, CHUNK_SIZE=np.array([25, 25, 25]),
+        MAJOR_VOXEL_SIZE=0.35, TARL_NORM=False)
     mod("utils")
     mod("utils.image")
     mod("utils.image.image_utils", dinov2_mean=lambda p2d: p2d, image_based_features_per_patch=image_features)
     mod("utils.point_cloud")
     mod("utils.point_cloud.chunk_generation",
-        get_indices_feature_reprojection=lambda idx, first, adjacent_frames: (list(idx[:3]), None),
-        tarl_features_per_patch=lambda dataset, chunk_major, T_pcd, center, tarl_idx: calls.setdefault("tarl", ch["tarl"]))
+        get_indices_feature_reprojection=lambda idx, first, adjacent_frames: (list(idx[:3]), None))
     mod("utils.point_cloud.point_cloud_utils",
         get_statistical_inlier_indices=lambda pcd: np.arange(pcd.points.shape[0]),
-        get_subpcd=lambda pcd, idx: PC(pcd.points[idx], pcd.colors[idx]))
+        get_subpcd=lambda pcd, idx: PC(pcd.points[idx], pcd.colors[idx]),
+        transform_pcd=lambda pts, T: np.asarray(pts) @ T[:3, :3].T + T[:3, 3])
+
+    class Dataset:
+        """Three lidar scans whose points carry the surrogate TARL feature of the nearest chunk point
+        (float32, as the .bin files hold them), each in its own sensor frame."""
+        def __init__(self):
+            r = np.random.default_rng(5)
+            self.scans = {}
+            for k in range(3):
+                sel = r.choice(ch["points"].shape[0], 9000, replace=True)
+                world = ch["points"][sel] + r.normal(0, 0.05, (9000, 3))
+                pose = np.eye(4)
+                pose[:3, 3] = [0.5 * k, -0.3 * k, 0.1]
+                self.scans[k] = (world - pose[:3, 3], ch["tarl"][sel].astype(np.float32), pose)
+
+        def get_tarl_features(self, i):
+            calls["tarl"] = calls.get("tarl", 0) + 1
+            return self.scans[i][1]
+
+        def get_point_cloud(self, i):
+            return self.scans[i][0]
+
+        def get_pose(self, i):
+            return self.scans[i][2]
+
+    dataset = Dataset()
+    from oracle import points_ref
+    world = [dataset.scans[k][0] + dataset.scans[k][2][:3, 3] for k in range(3)]
+    inbox = [np.all(w > -12.5, axis=1) & np.all(w < 12.5, axis=1) for w in world]
+    pooled = points_ref.tarl_pool(ch["points"], np.concatenate([w[m] for w, m in zip(world, inbox)]),
+                                  np.concatenate([dataset.scans[k][1][m] for k, m in enumerate(inbox)]), radius=0.175)
     mod("utils.visualization_utils", generate_random_colors=lambda n: [(int(37 * i) % 256, int(91 * i) % 256, 1 + i % 255) for i in range(n)])
 
     chunk_major, pcd_chunk, pcd_ground = PC(ch["points"]), PC(fine), PC(ground)
@@ -392,11 +423,11 @@ def test_ncuts_chunk_drop_in_with_stand_in_pipeline_modules(api, monkeypatch, be
          "pcd_nonground_chunks": [pcd_chunk], "pcd_ground_chunks": [pcd_ground],
          "pcd_nonground_chunks_major_downsampling": [chunk_major],
          "kitti_labels": {"ground": {"instance": [np.arange(400)], "semantic": [np.full(400, 40)]}}}
-    merged, chunk_out, cut, inst_g, seg_g = api.ncuts_chunk(None, d, None, np.eye(4), list(range(20)), sequence=0, patchwise_indices=[[3, 4]])
-    assert "tarl" in calls and chunk_out is pcd_chunk
+    merged, chunk_out, cut, inst_g, seg_g = api.ncuts_chunk(dataset, d, None, np.eye(4), list(range(20)), sequence=0, patchwise_indices=[[3, 4]])
+    assert calls.get("tarl") == 3 and chunk_out is pcd_chunk
     assert calls.get("image") == ((bool(beta), bool(gamma), bool(gamma) and not beta) if (beta or gamma) else None)
     # the fine cloud carries the colour of the nearest major-voxel point; groups are painted with distinct colours
-    groups = api.ncuts(ch["points"], ch["tarl"], ch["dino"] if gamma else None, sam=sam_ids if beta else None, alpha=1.0, theta=0.5,
+    groups = api.ncuts(ch["points"], pooled, ch["dino"] if gamma else None, sam=sam_ids if beta else None, alpha=1.0, theta=0.5,
                        gamma=gamma, beta=beta, T=0.03)
     assert np.unique(chunk_out.colors, axis=0).shape[0] == len(groups)
     from scipy.spatial import cKDTree
