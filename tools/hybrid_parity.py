@@ -6,7 +6,7 @@ answer is an arbitrary null-space vector).  If hybrid == model (the NumPy model 
 algorithm, Lanczos on connected segments) then every connected solve led to the same cut, and the
 only source of oracle-vs-device differences is SciPy's arbitrary choice in the null space.
 
-    python tools/hybrid_parity.py N [tarl|spatial]
+    python tools/hybrid_parity.py N [tarl|spatial] [seed]
 """
 import sys, time, json
 import numpy as np
@@ -18,7 +18,8 @@ import gpu_model
 
 n = int(sys.argv[1]); mode = sys.argv[2] if len(sys.argv) > 2 else "tarl"
 theta, T = (0.5, 0.03) if mode == "tarl" else (0.0, 0.075)
-ch = synth.synthetic_chunk(n, 0, tarl=(mode == "tarl"))
+seed = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+ch = synth.synthetic_chunk(n, seed, tarl=(mode == "tarl"))
 A = ncuts_ref.affinity_sparse(ch["points"], ch["tarl"], alpha=1.0, theta=theta, gamma=0.0)
 cnt = {"eigsh": 0, "null": 0}
 
@@ -40,6 +41,6 @@ t0 = time.time(); gh = hybrid(A, np.arange(n)); th = time.time() - t0
 t0 = time.time(); gm = gpu_model.normalized_cut_model(A, n, np.arange(n), T=T); tm = time.time() - t0
 lh, lm = ncuts_ref.groups_to_labels(gh, n), ncuts_ref.groups_to_labels(gm, n)
 same_order = len(gh) == len(gm) and all(np.array_equal(a, b) for a, b in zip(gh, gm))
-print(json.dumps({"n": n, "mode": mode, "hybrid_groups": len(gh), "model_groups": len(gm), "partition_equal": bool(ncuts_ref.partitions_equal(lh, lm)),
+print(json.dumps({"n": n, "mode": mode, "seed": seed, "hybrid_groups": len(gh), "model_groups": len(gm), "partition_equal": bool(ncuts_ref.partitions_equal(lh, lm)),
                   "same_group_order": bool(same_order), "ARI": ncuts_ref.adjusted_rand_index(lh, lm), "eigsh_calls": cnt["eigsh"], "null_solves": cnt["null"],
                   "hybrid_s": th, "model_s": tm}))
