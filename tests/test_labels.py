@@ -218,3 +218,33 @@ def test_merge_equals_oracle(ctx, seed):
     P, Cc = labels_api.merge_chunks_unite_instances2(chunks, ctx=ctx)
     eP, eC = merge_ref.merge_chunks_unite_instances2(chunks)
     assert np.array_equal(P, eP) and np.array_equal(Cc, eC)
+
+
+def test_host_scorer_arithmetic_property(monkeypatch):
+    """Random small label arrays (incl. no background, everything background, -1 labels, tiny min_points):
+    the product's scorer arithmetic on a NumPy contingency table == the pinned oracle."""
+    from hypothesis import given, settings, strategies as st
+    from autoinst_amd import labels_api
+    monkeypatch.setattr(labels_api, "label_pairs", np_label_pairs)
+
+    @settings(max_examples=120, deadline=None)
+    @given(st.integers(1, 60), st.integers(0, 2 ** 31 - 1), st.integers(1, 6), st.integers(1, 6), st.integers(1, 8), st.booleans())
+    def check(n, seed, kp, kg, min_points, with_bg):
+        rng = np.random.default_rng(seed)
+        gt = rng.integers(0 if with_bg else 1, kg + 1, n)
+        pred = rng.integers(-1 if seed % 3 == 0 else 0, kp + 1, n)
+        alll = np.where(rng.random(n) < 0.5, pred, rng.integers(0, kp + 2, n))
+        def run(f):
+            try:
+                return f(alll, pred, gt, min_points), None
+            except ZeroDivisionError as e:     # the reference divides by tp + fn as well (metrics_class.py:229)
+                return None, type(e)
+        (got, ge), (exp, ee) = run(labels_api.score), run(metrics_ref.score)
+        assert ge == ee
+        if exp is None:
+            return
+        for k, v in exp.items():
+            a, b = got[k], v
+            assert (a == b) or (isinstance(a, float) and isinstance(b, float) and np.isnan(a) and np.isnan(b)), (k, a, b)
+
+    check()
