@@ -248,3 +248,26 @@ def test_host_scorer_arithmetic_property(monkeypatch):
             assert (a == b) or (isinstance(a, float) and isinstance(b, float) and np.isnan(a) and np.isnan(b)), (k, a, b)
 
     check()
+
+
+@pytest.mark.gpu
+def test_merge_equals_oracle_on_random_small_maps(ctx):
+    """Randomised small maps: coincident points between chunks, instances that are all street, shared
+    coordinate values on a coarse grid (so the 'distinct scalars' union really overlaps), -0.0."""
+    from autoinst_amd import labels_api
+    rng = np.random.default_rng(77)
+    for case in range(25):
+        n_chunks = int(rng.integers(2, 4))
+        base = np.round(rng.normal(0, 6, (int(rng.integers(30, 400)), 3)) * 4) / 4      # 0.25 m grid: many shared scalars
+        base[rng.random(base.shape) < 0.02] *= -0.0
+        chunks = []
+        for c in range(n_chunks):
+            sel = rng.random(base.shape[0]) < 0.7
+            pts = base[sel] + (0.0 if rng.random() < 0.6 else np.round(rng.normal(0, 0.5, 3) * 4) / 4)
+            k = int(rng.integers(1, 6))
+            inst = rng.integers(0, k + 1, pts.shape[0])                                    # 0 = street
+            pal = np.concatenate([np.zeros((1, 3)), palette(k, 1000 * case + c)])
+            chunks.append((pts, pal[inst]))
+        P, Cc = labels_api.merge_chunks_unite_instances2(chunks, ctx=ctx)
+        eP, eC = merge_ref.merge_chunks_unite_instances2(chunks)
+        assert np.array_equal(P, eP) and np.array_equal(Cc, eC), case
