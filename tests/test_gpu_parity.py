@@ -493,3 +493,33 @@ def test_sam_factor_matches_oracle(api):
         api.get_affinity_matrix(pts, tarl, None, alpha=1.0, theta=0.5, gamma=0.0, beta=0.5)
     groups = api.ncuts(pts, tarl, None, sam=sam, alpha=1.0, theta=0.5, gamma=0.0, beta=0.7, T=0.03)
     assert sorted(np.concatenate(groups).tolist()) == list(range(n))
+
+
+def test_random_small_clouds_device_equals_model(api):
+    """Forty random clouds (50-3000 points, blobs / sheets / lines, several T and radii): the HIP path
+    and the NumPy model of the same algorithm give the same partition (small segments take the
+    dense-check path, sparse rows exhaust the encoder's pool, single points stay single)."""
+    rng = np.random.default_rng(2024)
+    bad = []
+    for case in range(40):
+        n = int(rng.integers(50, 3000))
+        kind = case % 4
+        if kind == 0:      # a few blobs
+            c = rng.normal(0, 4, (int(rng.integers(2, 7)), 3))
+            pts = c[rng.integers(0, c.shape[0], n)] + rng.normal(0, rng.uniform(0.3, 1.2), (n, 3))
+        elif kind == 1:    # a bumpy sheet
+            xy = rng.uniform(-8, 8, (n, 2))
+            pts = np.c_[xy, 0.3 * np.sin(xy[:, 0]) + rng.normal(0, 0.05, n)]
+        elif kind == 2:    # line segments (sparse rows)
+            t = rng.uniform(0, 30, n)
+            pts = np.c_[t, np.floor(t / 10) * 3.0 + rng.normal(0, 0.05, n), rng.normal(0, 0.05, n)]
+        else:              # uniform box with isolated points
+            pts = rng.uniform(-6, 6, (n, 3))
+        T = float(rng.choice([0.01, 0.05, 0.2]))
+        A = ncuts_ref.affinity_sparse(pts, None, alpha=1.0, theta=0.0, gamma=0.0)
+        got = api.normalized_cut(A, n, np.arange(n), T=T)
+        exp = gpu_model.normalized_cut_model(A, n, np.arange(n), T=T)
+        la, lb = ncuts_ref.groups_to_labels(got, n), ncuts_ref.groups_to_labels(exp, n)
+        if not ncuts_ref.partitions_equal(la, lb):
+            bad.append((case, n, kind, T, len(got), len(exp), ncuts_ref.adjusted_rand_index(la, lb)))
+    assert not bad, bad
