@@ -174,3 +174,46 @@ def test_sam_factor_sparse_equals_literal_dense():
     assert (A.data < B.data - 1e-6).any() and np.all(A.data <= B.data + 1e-15)
     with pytest.raises(ValueError):
         ncuts_ref.affinity_sparse(pts, tarl, None, alpha=1.0, theta=0.5, gamma=0.0, beta=0.7)
+
+
+def test_random_small_clouds_model_equals_reference_with_eigsh():
+    """Thirty random clouds: the model of the device algorithm == the reference recursion with SciPy's
+    shift-invert eigsh on every connected segment (and the device's null-space rule on disconnected ones),
+    same groups in the same order."""
+    from scipy.sparse.csgraph import connected_components
+    rng = np.random.default_rng(99)
+    bad = []
+    for case in range(30):
+        n = int(rng.integers(60, 1500))
+        kind = case % 3
+        if kind == 0:
+            c = rng.normal(0, 4, (int(rng.integers(2, 6)), 3))
+            pts = c[rng.integers(0, c.shape[0], n)] + rng.normal(0, rng.uniform(0.3, 1.0), (n, 3))
+        elif kind == 1:
+            xy = rng.uniform(-7, 7, (n, 2))
+            pts = np.c_[xy, 0.3 * np.sin(xy[:, 0]) + rng.normal(0, 0.05, n)]
+        else:
+            pts = rng.uniform(-5, 5, (n, 3))
+        T = float(rng.choice([0.02, 0.1, 0.3]))
+        A = ncuts_ref.affinity_sparse(pts, None, alpha=1.0, theta=0.0, gamma=0.0)
+
+        def hybrid(w, labels):
+            if w.shape[0] > 2 and labels.shape[0] / (n + 1e-8) > 0.01:
+                nc, comp = connected_components(w, directed=False)
+                if nc > 1:
+                    d = np.asarray(w.sum(axis=0)).ravel() + 1.0
+                    ev = gpu_model.null_vector(w, nc, comp)
+                else:
+                    _, ev, d = ncuts_ref.fiedler(w)
+                    ev = gpu_model.fix_sign(ev)
+                mask, mcut, _ = gpu_model.sweep(ev, d, w)
+                if mcut < T:
+                    return hybrid(w[mask][:, mask], labels[mask]) + hybrid(w[~mask][:, ~mask], labels[~mask])
+            return [labels]
+
+        gh = hybrid(A, np.arange(n))
+        gm = gpu_model.normalized_cut_model(A, n, np.arange(n), T=T)
+        if not (len(gh) == len(gm) and all(np.array_equal(a, b) for a, b in zip(gh, gm))):
+            la, lb = ncuts_ref.groups_to_labels(gh, n), ncuts_ref.groups_to_labels(gm, n)
+            bad.append((case, n, kind, T, len(gh), len(gm), float(ncuts_ref.adjusted_rand_index(la, lb))))
+    assert not bad, bad
