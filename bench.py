@@ -88,7 +88,7 @@ def cpu_baseline(seconds_budget: float = 30.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--in-flight", type=int, default=4, help="host threads (contexts) per GPU")
     ap.add_argument("--batch", type=int, default=6, help="chunks per batched call (root segments of one frontier)")
@@ -121,9 +121,10 @@ def main():
     # K*B different chunks (seeds 0..K*B-1), all resident in HBM.  Every rank works on the SAME set, so
     # the per-GPU work is exactly fixed as N grows (weak scaling); one chunk costs 26-59 ms depending
     # on its seed, and a real map's spread is what sharding.lpt_assign balances.
-    for i in range(K * B):
-        ch = synth.synthetic_chunk(N_POINTS, seed=i, tarl=True)
-        data.append((torch.from_numpy(ch["points"]).to(dev), torch.from_numpy(ch["tarl"]).to(dev)))
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=4) as gen:   # set-up only: ~2 s of NumPy per chunk
+        for ch in gen.map(lambda i: synth.synthetic_chunk(N_POINTS, seed=i, tarl=True), range(K * B)):
+            data.append((torch.from_numpy(ch["points"]).to(dev), torch.from_numpy(ch["tarl"]).to(dev)))
     torch.cuda.synchronize()
 
     def one_batch(k, profile=False, only_first=False):
