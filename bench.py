@@ -217,6 +217,7 @@ def main():
     for t in workers:
         t.join()
 
+    free_b, total_b = torch.cuda.mem_get_info(dev)
     if rank == 0:
         assert merged is not None and len(merged) == world * K * B and all(v.shape[0] == N_POINTS for v in merged.values())
         launches = int(stp["lanczos_steps"])
@@ -240,6 +241,7 @@ def main():
                                    f"alpha=1 theta=0.5 T=0.03; per GPU per step {K} host threads x {B} chunks batched into one frontier",
                        "n_points": N_POINTS, "nnz": int(nnz), "chunks_per_step": world * K * B, "threads_per_gpu": K, "chunks_per_batch": B,
                        "parallelism": f"chunk-dp{world}"},
+            "hbm_in_use_gb": (total_b - free_b) / 1e9,   # inputs + K workspaces (arena, cached graph buffers) + torch
             "single_chunk_latency_ms": latency_ms,
             "batch_ncut_ms": stb["ms_total"],
             "eigensolve_ms": st["ms_eigen"],
