@@ -48,3 +48,19 @@ def test_product_does_not_import_the_oracle():
         if f.endswith(".py"):
             src = open(os.path.join(pkg, f)).read()
             assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/autoinst_hip.h is a C header (extern "C" only under __cplusplus): a C99 compiler accepts it and
+    every declared entry point can be referenced from C."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "use.c"
+    body = "\n".join(f"  p[{i}] = (fn){name};" for i, name in enumerate(_ffi.SYMBOLS))
+    src.write_text('#include "autoinst_hip.h"\ntypedef void (*fn)(void);\nfn p[%d];\nvoid fill(void) {\n%s\n}\n'
+                   % (len(_ffi.SYMBOLS), body))
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), "-c", str(src),
+                        "-o", str(tmp_path / "use.o")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
