@@ -64,3 +64,23 @@ def test_header_is_plain_c(tmp_path):
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), "-c", str(src),
                         "-o", str(tmp_path / "use.o")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_c_program_links_and_runs(tmp_path):
+    """A C program links against libautoinst_hip.so directly (no Python, no torch) and calls into it."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    _ffi.load()
+    src = tmp_path / "main.c"
+    src.write_text('#include <stdio.h>\n#include "autoinst_hip.h"\nint main(void) {\n  printf("%d|%s\\n", ai_version(), ai_last_error());\n'
+                   '  return ai_ctx_destroy(0);\n}\n')
+    libdir = os.path.dirname(_ffi.LIB_PATH)
+    exe = tmp_path / "main"
+    r = subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-L", libdir, "-lautoinst_hip",
+                        "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip().split("|")[0] == str(_ffi.load().ai_version())
