@@ -523,3 +523,57 @@ def test_random_small_clouds_device_equals_model(api):
         if not ncuts_ref.partitions_equal(la, lb):
             bad.append((case, n, kind, T, len(got), len(exp), ncuts_ref.adjusted_rand_index(la, lb)))
     assert not bad, bad
+
+
+def test_pure_c_caller_gets_the_same_labels(api, tmp_path):
+    """The boundary is the C ABI: a C program (no Python, no torch in the process) builds the graph and runs
+    the recursion through include/autoinst_hip.h and gets the labels the Python mirror returns."""
+    import shutil
+    import subprocess
+    from autoinst_amd import _ffi, synth
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    ch = synth.synthetic_chunk(8000, 41, tarl=True)
+    n = ch["points"].shape[0]
+    (tmp_path / "pts.bin").write_bytes(np.ascontiguousarray(ch["points"]).tobytes())
+    (tmp_path / "tarl.bin").write_bytes(np.ascontiguousarray(ch["tarl"]).tobytes())
+    src = tmp_path / "caller.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <stdlib.h>
+#include "autoinst_hip.h"
+static void* slurp(const char* path, size_t bytes) {
+  void* p = malloc(bytes); FILE* f = fopen(path, "rb");
+  if (!p || !f || fread(p, 1, bytes, f) != bytes) { fprintf(stderr, "cannot read %s\n", path); exit(2); }
+  fclose(f); return p;
+}
+int main(int argc, char** argv) {
+  long n = atol(argv[1]);
+  double* pts = slurp(argv[2], (size_t)n * 3 * sizeof(double));
+  double* tarl = slurp(argv[3], (size_t)n * 96 * sizeof(double));
+  ai_ctx* ctx = 0; ai_csr* g = 0;
+  if (ai_ctx_create(0, &ctx)) { fprintf(stderr, "%s\n", ai_last_error()); return 1; }
+  if (ai_affinity_build(ctx, pts, n, tarl, 96, 0, 0, 1.0, 0.5, 0.0, 1.0, AI_MEM_HOST, &g)) { fprintf(stderr, "%s\n", ai_last_error()); return 1; }
+  int32_t* lab = malloc((size_t)n * sizeof(int32_t)); int32_t ng = 0; ai_ncut_stats st;
+  if (ai_ncut(ctx, g, n, 0.03, 0.01, 0, lab, &ng, &st)) { fprintf(stderr, "%s\n", ai_last_error()); return 1; }
+  FILE* f = fopen(argv[4], "wb"); fwrite(lab, sizeof(int32_t), (size_t)n, f); fclose(f);
+  printf("%d %lld\n", ng, (long long)st.unconverged);
+  ai_csr_free(ctx, g); ai_ctx_destroy(ctx);
+  return 0;
+}
+''')
+    libdir = os.path.dirname(_ffi.LIB_PATH)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "caller"
+    r = subprocess.run(["gcc", "-std=c99", "-I", os.path.join(root, "include"), str(src), "-o", str(exe), "-L", libdir, "-lautoinst_hip",
+                        "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([str(exe), str(n), str(tmp_path / "pts.bin"), str(tmp_path / "tarl.bin"), str(tmp_path / "lab.bin")],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    ng_c, unconv = (int(x) for x in out.stdout.split())
+    lab_c = np.fromfile(tmp_path / "lab.bin", dtype=np.int32)
+    g = api.build_affinity(ch["points"], ch["tarl"], alpha=1.0, theta=0.5, gamma=0.0)
+    lab_py, ng_py, _ = api.ncuts_labels(g, n, 0.03)
+    g.free()
+    assert unconv == 0 and ng_c == ng_py and np.array_equal(lab_c, lab_py)
