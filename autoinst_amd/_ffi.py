@@ -21,7 +21,7 @@ SYMBOLS = (
     "ai_csr_from_host", "ai_csr_dims", "ai_csr_export", "ai_csr_free", "ai_ncut", "ai_fiedler",
     "ai_sweep", "ai_lsym_apply", "ai_bench_spmv", "ai_eigs_smallest",
     "ai_radius_mean_pool", "ai_nn1_project", "ai_ncut_batch",
-    "ai_label_pairs", "ai_merge_associate", "ai_unique_points", "ai_affinity_build_sam",
+    "ai_label_pairs", "ai_merge_associate", "ai_unique_points", "ai_affinity_build_sam", "ai_affinity_apply_camera",
 )
 
 
@@ -70,6 +70,7 @@ def load():
     lib.ai_ctx_destroy.argtypes = [vp]
     lib.ai_affinity_build.argtypes = [vp, vp, i64, vp, i32, vp, i32, dbl, dbl, dbl, dbl, C.c_int, P(vp)]
     lib.ai_affinity_build_sam.argtypes = [vp, vp, i64, vp, i32, vp, i32, vp, i32, dbl, dbl, dbl, dbl, dbl, C.c_int, P(vp)]
+    lib.ai_affinity_apply_camera.argtypes = [vp, vp, vp, i32, vp, i32, dbl, dbl, C.c_int]
     lib.ai_csr_from_host.argtypes = [vp, i64, vp, vp, vp, P(vp)]
     lib.ai_csr_dims.argtypes = [vp, P(i64), P(i64)]
     lib.ai_csr_export.argtypes = [vp, vp, vp, vp, vp]

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(AI_BLOCK) void k_weights(const int32_t* __restrict_
                                                       const double* __restrict__ tarl, int32_t tdim,
                                                       const uint8_t* __restrict__ notarl, const double* __restrict__ dino,
                                                       int32_t ddim, double alpha, double theta, double gamma,
-                                                      const int32_t* __restrict__ sam, int32_t nviews, double beta) {
+                                                      const int32_t* __restrict__ sam, int32_t nviews, double beta, int extra) {
   // workgroups are dealt round-robin to the 8 XCDs: remap so that each XCD walks one contiguous eighth of
   // the Morton-ordered rows and the neighbours' feature rows are re-used from ITS 4 MB L2 (the 154 MB
   // feature matrix itself only fits the Infinity Cache)
@@ -265,9 +265,10 @@ __global__ __launch_bounds__(AI_BLOCK) void k_weights(const int32_t* __restrict_
     const int32_t e = eb + 4 * t + grp;
     if (e < e1) {
       const double d = val[e];
-      double w = 1.0;
+      // extra = 1: val[] already holds the affinity and one more camera's SAM / DINO factors multiply it
+      double w = extra ? d : 1.0;
       if (use_t) w = exp(-theta * sqrt(my_t2));
-      if (alpha != 0.0) w = w * exp(-alpha * d);
+      if (!extra && alpha != 0.0) w = w * exp(-alpha * d);
       if (sam != nullptr && beta != 0.0) {
         // SAM factor (utils/image/image_utils.py:64-89): fraction of the views in which both points carry an
         // id (!= -1) and the ids differ
@@ -493,7 +494,7 @@ extern "C" int ai_affinity_build_sam(ai_ctx* ctx, const double* xyz, int64_t n, 
 #define AI_LAUNCH_W(TK, DK)                                                                                                          \
   hipLaunchKernelGGL((k_weights<TK, DK>), dim3(gw), dim3(AI_BLOCK), 0, st, (const int32_t*)A->rowptr, (const int32_t*)A->col, A->val, \
                      (const int32_t*)A->orig, n, d_tarl, tarl_dim, (const uint8_t*)notarl.p, d_dino, dino_dim, alpha, theta, gamma, d_sam, \
-                     sam_views, beta)
+                     sam_views, beta, 0)
     if (t96 && d384)
       AI_LAUNCH_W(6, 24);
     else if (t96)
@@ -510,4 +511,45 @@ extern "C" int ai_affinity_build_sam(ai_ctx* ctx, const double* xyz, int64_t n, 
   return AI_OK;
 #undef AI_TRYF
 #undef AI_HIPF
+}
+
+// One more camera's factors on an existing graph (ncuts_utils.py:118-123 and :128-133 loop over the cameras):
+// every stored value is multiplied by exp(-beta * sam fraction) * exp(-gamma * ||dino_i - dino_j||).
+extern "C" int ai_affinity_apply_camera(ai_ctx* ctx, ai_csr* csr, const double* dino, int32_t dino_dim, const int32_t* sam,
+                                        int32_t sam_views, double beta, double gamma, int mem_kind) {
+  if (!ctx || !csr || (gamma != 0.0 && (!dino || dino_dim <= 0)) || (beta != 0.0 && (!sam || sam_views <= 0))) {
+    ai_set_error("ai_affinity_apply_camera: bad argument (a non-zero weight needs its feature matrix)");
+    return AI_ERR_BAD_ARG;
+  }
+  if (gamma == 0.0 && beta == 0.0) return AI_OK;
+  AI_HIP(hipSetDevice(ctx->device));
+  ArenaScope arena_scope(&ctx->arena);
+  hipStream_t st = ctx->stream;
+  const int64_t n = csr->n;
+  DevBuf<double> own_dino;
+  DevBuf<int32_t> own_sam;
+  const double* d_dino = nullptr;
+  const int32_t* d_sam = nullptr;
+  AI_TRY(upload_if_host(gamma != 0.0 ? dino : nullptr, (size_t)n * (size_t)(dino_dim > 0 ? dino_dim : 0), mem_kind, own_dino, &d_dino, st));
+  if (beta != 0.0) {
+    if (mem_kind == AI_MEM_DEVICE) {
+      d_sam = sam;
+    } else {
+      AI_TRY(own_sam.alloc((size_t)n * sam_views));
+      AI_HIP(hipMemcpyAsync(own_sam.p, sam, (size_t)n * sam_views * sizeof(int32_t), hipMemcpyHostToDevice, st));
+      d_sam = own_sam.p;
+    }
+  }
+  const unsigned gw = (unsigned)((n + (AI_BLOCK / 64) - 1) / (AI_BLOCK / 64));
+  if (d_dino && dino_dim == 384)
+    hipLaunchKernelGGL((k_weights<0, 24>), dim3(gw), dim3(AI_BLOCK), 0, st, (const int32_t*)csr->rowptr, (const int32_t*)csr->col, csr->val,
+                       (const int32_t*)csr->orig, n, (const double*)nullptr, 0, (const uint8_t*)nullptr, d_dino, dino_dim, 0.0, 0.0, gamma, d_sam,
+                       sam_views, beta, 1);
+  else
+    hipLaunchKernelGGL((k_weights<0, 0>), dim3(gw), dim3(AI_BLOCK), 0, st, (const int32_t*)csr->rowptr, (const int32_t*)csr->col, csr->val,
+                       (const int32_t*)csr->orig, n, (const double*)nullptr, 0, (const uint8_t*)nullptr, d_dino, dino_dim, 0.0, 0.0, gamma, d_sam,
+                       sam_views, beta, 1);
+  AI_HIP(hipGetLastError());
+  AI_HIP(hipStreamSynchronize(st));
+  return AI_OK;
 }

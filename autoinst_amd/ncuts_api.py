@@ -149,10 +149,17 @@ def build_affinity(points, tarl=None, dino=None, *, alpha=CONFIG["alpha"], theta
     already live on the context's GPU (used in place; PyTorch here is only the owner of the HBM buffer).
     """
     ctx = ctx or default_context()
-    if gamma and dino is None:
+    # one matrix per camera (ncuts_utils.py:118-123, :128-133 loop over them); a bare array is one camera
+    dino_list = list(dino) if isinstance(dino, (list, tuple)) else ([] if dino is None else [dino])
+    sam_list = list(sam) if isinstance(sam, (list, tuple)) else ([] if sam is None else [sam])
+    if gamma and not dino_list:
         raise ValueError("The length should be longer than 0!")  # ncuts_utils.py:126-127
-    if beta and sam is None:
+    if beta and not sam_list:
         raise ValueError("The length should be longer than 0!")  # ncuts_utils.py:116-117
+    dino = dino_list[0] if (gamma and dino_list) else None
+    sam = sam_list[0] if (beta and sam_list) else None
+    extra_dino = dino_list[1:] if gamma else []
+    extra_sam = sam_list[1:] if beta else []
     if theta and tarl is None:
         raise ValueError("theta != 0 needs TARL features")
     on_dev = _is_device_tensor(points)
@@ -193,7 +200,26 @@ def build_affinity(points, tarl=None, dino=None, *, alpha=CONFIG["alpha"], theta
         ptr(sm), sm.shape[1] if sm is not None else 0, float(alpha or 0.0), float(beta or 0.0), float(gamma or 0.0),
         float(theta or 0.0), float(radius), mem, C.byref(h))
     _ffi.check(st, "ai_affinity_build")
-    return DeviceGraph(ctx, h)
+    graph = DeviceGraph(ctx, h)
+    for c in range(max(len(extra_dino), len(extra_sam))):
+        ed = extra_dino[c] if c < len(extra_dino) else None
+        es = extra_sam[c] if c < len(extra_sam) else None
+        if on_dev:
+            import torch
+            ed = _dev_f64(ed, None, "dino") if ed is not None else None
+            if es is not None and (not _is_device_tensor(es) or es.dtype != torch.int32 or not es.is_contiguous()):
+                raise ValueError("points are on the device, so sam must be a contiguous int32 tensor there too")
+        else:
+            ed = _as_f64(ed, None, "dino") if ed is not None else None
+            es = np.ascontiguousarray(np.asarray(es), dtype=np.int32) if es is not None else None
+        for f, nm in ((ed, "dino"), (es, "sam")):
+            if f is not None and f.shape[0] != n:
+                graph.free()
+                raise ValueError(f"{nm} has {f.shape[0]} rows for {n} points")
+        _ffi.check(_ffi.load().ai_affinity_apply_camera(ctx._h, graph._h, ptr(ed), ed.shape[1] if ed is not None else 0, ptr(es),
+                                                        es.shape[1] if es is not None else 0, float(beta if es is not None else 0.0),
+                                                        float(gamma if ed is not None else 0.0), mem), "ai_affinity_apply_camera")
+    return graph
 
 
 def get_affinity_matrix(points, tarl=None, dino=None, *, alpha=CONFIG["alpha"], theta=CONFIG["theta"],
@@ -388,16 +414,12 @@ def ncuts_chunk(dataset, chunk_downsample_dict, pcd_nonground_minor, T_pcd, samp
     if cfg["beta"]:
         if len(sam_list) == 0:
             raise ValueError("The length should be longer than 0!")
-        if len(sam_list) != 1:
-            raise NotImplementedError("more than one camera (CAM_IDS has one entry, config.py:72)")
-        sam = np.asarray(sam_list[0])
+        sam = [np.asarray(x) for x in sam_list]
     if cfg["gamma"]:
         feats = [dinov2_mean(p2d) for p2d in point2dino_list]
         if len(feats) == 0:
             raise ValueError("The length should be longer than 0!")
-        if len(feats) != 1:
-            raise NotImplementedError("more than one camera (CAM_IDS has one entry, config.py:72)")
-        dino = feats[0]
+        dino = feats
     tarl = None
     if cfg["theta"]:
         # tarl_features_per_patch (chunk_generation.py:205-258): its per-point radius search and mean run on the device

@@ -77,6 +77,15 @@ int ai_affinity_build_sam(ai_ctx* ctx, const double* xyz, int64_t n, const doubl
                           double beta, double gamma, double theta, double radius, int mem_kind, ai_csr** out);
 
 /*
+ * One more camera (the loops over cameras at ncuts_utils.py:118-123 and :128-133; CAM_IDS has a single entry
+ * in the reference's config.py:72): multiplies every stored value of an existing graph by that camera's
+ * exp(-beta * SAM fraction) and exp(-gamma * ||dino_i - dino_j||).  The product is then associated
+ * ((... * cam1) * cam2) instead of the reference's (cam1 * cam2): values agree to 1 ulp.
+ */
+int ai_affinity_apply_camera(ai_ctx* ctx, ai_csr* csr, const double* dino, int32_t dino_dim, const int32_t* sam,
+                             int32_t sam_views, double beta, double gamma, int mem_kind);
+
+/*
  * Upload a caller-built symmetric CSR (what ncuts_utils.py:167 hands to
  * normalized_cut at :168).  indptr has n+1 entries.  Row order is kept.
  */

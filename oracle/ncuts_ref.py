@@ -76,10 +76,12 @@ def affinity_dense(points, tarl=None, dino=None, *, alpha=1.0, theta=0.0, gamma=
             cam_w, _ = sam_label_distance(np.asarray(sam_features_major), spatial_distance, radius, beta)
             sam_w = sam_w * cam_w
     if gamma:                                                       # :125-133
-        if dino is None:
+        dino_list = [] if dino is None else (list(dino) if isinstance(dino, (list, tuple)) else [dino])
+        if len(dino_list) == 0:
             raise ValueError("The length should be longer than 0!")  # :126-127
-        dino_distance = cdist(dino, dino)
-        dino_w = dino_w * np.exp(-gamma * dino_distance)
+        for dinov2_features_major in dino_list:                     # :128-133, one factor per camera
+            dino_distance = cdist(dinov2_features_major, dinov2_features_major)
+            dino_w = dino_w * np.exp(-gamma * dino_distance)
     if theta:                                                       # :135-147
         tarl = np.asarray(tarl, dtype=np.float64)
         no_tarl = ~np.array(tarl).any(1)
@@ -144,10 +146,13 @@ def affinity_sparse(points, tarl=None, dino=None, *, alpha=1.0, theta=0.0, gamma
             sam_w = sam_w * np.exp(-beta * frac)
         w = w * sam_w
     if gamma:
-        if dino is None:
+        dino_list = [] if dino is None else (list(dino) if isinstance(dino, (list, tuple)) else [dino])
+        if len(dino_list) == 0:
             raise ValueError("The length should be longer than 0!")
-        g = _rowwise_euclid(np.asarray(dino, dtype=np.float64), i, j)
-        w = w * np.exp(-gamma * g)
+        dino_w = np.ones_like(d)
+        for dn in dino_list:
+            dino_w = dino_w * np.exp(-gamma * _rowwise_euclid(np.asarray(dn, dtype=np.float64), i, j))
+        w = w * dino_w
     A = sp.csr_matrix((w, (i, j)), shape=(n, n))
     A.sum_duplicates()
     A.sort_indices()

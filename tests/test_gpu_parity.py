@@ -577,3 +577,22 @@ int main(int argc, char** argv) {
     lab_py, ng_py, _ = api.ncuts_labels(g, n, 0.03)
     g.free()
     assert unconv == 0 and ng_c == ng_py and np.array_equal(lab_c, lab_py)
+
+
+def test_two_cameras_match_oracle(api):
+    """Lists of per-camera matrices for the DINO and SAM factors (the reference loops over cameras; its config has
+    one): the extra cameras multiply the finished graph, values agree with the oracle to 1e-12."""
+    rng = np.random.default_rng(21)
+    n = 3000
+    pts = rng.normal(0, 2.5, (n, 3))
+    tarl = rng.normal(0, 1, (n, 96))
+    dino = [rng.normal(0, 1, (n, 384)), rng.normal(0, 1, (n, 384)), rng.normal(0, 1, (n, 384))]
+    sam = [rng.integers(-1, 4, (n, 5)), rng.integers(-1, 3, (n, 2))]
+    kw = dict(alpha=1.0, theta=0.5, gamma=0.05, beta=0.8)
+    A = api.get_affinity_matrix(pts, tarl, dino, sam=sam, **kw)
+    B = ncuts_ref.affinity_sparse(pts, tarl, dino, sam=sam, **kw)
+    assert np.array_equal(A.indptr, B.indptr) and np.array_equal(A.indices, B.indices)
+    assert (np.abs(A.data - B.data) / B.data).max() <= 1e-12
+    assert abs(A - A.T).max() == 0.0 and np.all(A.diagonal() == 1.0)
+    one = api.get_affinity_matrix(pts, tarl, dino[:1], sam=sam[:1], **kw)
+    assert (one.data >= A.data).all() and (one.data > A.data).any()

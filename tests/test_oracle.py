@@ -217,3 +217,15 @@ def test_random_small_clouds_model_equals_reference_with_eigsh():
             la, lb = ncuts_ref.groups_to_labels(gh, n), ncuts_ref.groups_to_labels(gm, n)
             bad.append((case, n, kind, T, len(gh), len(gm), float(ncuts_ref.adjusted_rand_index(la, lb))))
     assert not bad, bad
+
+
+def test_two_cameras_sparse_equals_literal_dense():
+    """The loops over cameras (ncuts_utils.py:118-123, :128-133): one SAM and one DINO factor per camera."""
+    rng = np.random.default_rng(6)
+    pts = rng.normal(0, 1.2, (140, 3))
+    dino = [rng.normal(0, 1, (140, 384)), rng.normal(0, 1, (140, 384))]
+    sam = [_sam_ids(140, 4, 1), _sam_ids(140, 3, 2)]
+    kw = dict(alpha=1.0, theta=0.0, gamma=0.05, beta=0.9)
+    D = ncuts_ref.affinity_dense(pts, None, dino, sam=sam, **kw)
+    A = ncuts_ref.affinity_sparse(pts, None, dino, sam=sam, **kw)
+    assert np.array_equal(A.toarray() != 0, D != 0) and np.abs(A.toarray() - D).max() <= 1e-15
