@@ -46,6 +46,10 @@ class AutoinstHipError(RuntimeError):
     pass
 
 
+class NoConvergence(AutoinstHipError):
+    """A Lanczos solve hit max_iter (status -3); the reference raises scipy's ArpackNoConvergence there."""
+
+
 _lib = None
 
 
@@ -102,4 +106,6 @@ def check(status: int, what: str):
         raise ValueError(f"{what}: {msg}")
     if status == -2:
         raise MemoryError(f"{what}: {msg}")
+    if status == -3:
+        raise NoConvergence(f"{what}: {msg}")
     raise AutoinstHipError(f"{what} failed (status {status}): {msg}")

@@ -2725,6 +2725,12 @@ static int ncut_impl(ai_ctx* ctx, const ai_csr* csr, int nchunks, const int64_t*
   }
   S.stats.ms_total = now_ms() - t0;
   if (stats_out) *stats_out = S.stats;
+  if (S.stats.unconverged > 0) {
+    // the reference's eigsh raises ArpackNoConvergence (normalized_cut.py:49); labels and stats are filled all the same
+    ai_set_error("ai_ncut: %lld Lanczos solve(s) reached max_iter = %d before the Ritz residual fell to %.3g (largest %.3g)",
+                 (long long)S.stats.unconverged, S.opt.max_iter, S.opt.tol, S.stats.max_resid);
+    return AI_ERR_NO_CONVERGENCE;
+  }
   return AI_OK;
 }
 

@@ -140,6 +140,9 @@ typedef struct {
  * (mask side first); *n_groups receives their number.  split_lim applies to the top
  * call only; deeper calls use 0.01 as the reference does (:57-58 rely on the default).
  * opts / stats may be NULL.
+ * A solve that reaches opts->max_iter before its residual falls to opts->tol makes the call return
+ * AI_ERR_NO_CONVERGENCE (the reference's eigsh raises ArpackNoConvergence, normalized_cut.py:49); labels,
+ * n_groups and stats (stats->unconverged, max_resid) are filled from the best vectors all the same.
  */
 int ai_ncut(ai_ctx* ctx, const ai_csr* csr, int64_t num_points_orig, double T, double split_lim,
             const ai_ncut_opts* opts, int32_t* labels_out, int32_t* n_groups, ai_ncut_stats* stats);

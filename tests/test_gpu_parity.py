@@ -596,3 +596,16 @@ def test_two_cameras_match_oracle(api):
     assert abs(A - A.T).max() == 0.0 and np.all(A.diagonal() == 1.0)
     one = api.get_affinity_matrix(pts, tarl, dino[:1], sam=sam[:1], **kw)
     assert (one.data >= A.data).all() and (one.data > A.data).any()
+
+
+def test_no_convergence_is_an_error_like_the_reference(api):
+    """A step cap too small for the residual tolerance: status -3 -> NoConvergence (a RuntimeError, as scipy's
+    ArpackNoConvergence is at normalized_cut.py:49)."""
+    from autoinst_amd import _ffi, synth
+    ch = synth.synthetic_chunk(6000, 3, tarl=False)
+    g = api.build_affinity(ch["points"], None, alpha=1.0, theta=0.0, gamma=0.0)
+    with pytest.raises(_ffi.NoConvergence, match="max_iter"):
+        api.ncuts_labels(g, g.n, 0.075, max_iter=5)
+    lab, ng, st = api.ncuts_labels(g, g.n, 0.075)          # the context is still usable afterwards
+    assert st["unconverged"] == 0 and ng >= 1
+    g.free()
