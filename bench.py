@@ -4,28 +4,39 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches the N ranks
+itself (one child process per GPU, started BEFORE this process imports torch or touches HIP; the
+parent only waits, relays rank 0's JSON line and returns non-zero if any rank failed).
+
 One "step" = one pass of the hot path over one batch of chunks per GPU: `--in-flight` (4) host
 threads, each with its own context / HIP streams, each pushing `--batch` (6) independent chunks
 through ONE batched call (the chunks are the root segments of one frontier and share every kernel
 launch): affinity build (TARL + spatial) from inputs already resident in HBM, recursive normalized
-cut, labels back on the host, and (N > 1) the gather of the label arrays to rank 0.  One chunk
-alone is latency-bound (thousands of dependent launches on small frontiers); its latency is
-reported next to the throughput, and the per-chunk counters / roofline come from that single run.  Workload = BASELINE.json configs[1]: a 200 000-point
-chunk, alpha = 1, theta = 0.5 (96-d features), T = 0.03; synthetic surface chunk.
-Chunks are independent, so ranks process different chunks with no data-path collective
-("weak" scaling: the same number of chunks per rank per step).
+cut, labels back on the host, and (N > 1) the gather of the label arrays to rank 0.  Workload =
+BASELINE.json configs[1]: a 200 000-point chunk, alpha = 1, theta = 0.5 (96-d features), T = 0.03;
+synthetic surface chunk.  Chunks are independent (reference `pipeline/run_pipeline.py:160-179`),
+so the world's chunk list is dealt to the ranks by `sharding.lpt_assign` and there is no data-path
+collective ("weak" scaling: the same number of chunks per rank per step).
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the fused Lanczos SpMV,
-`k_lz_spmv_x`): algorithmic bytes of its launches / their summed duration, both from a profiled
-repeat of one batched call with HIP start/stop events on every dispatch (library's stream).
-`cpu_baseline` is the oracle (NumPy / SciPy restatement, scipy eigsh shift-invert as the
-reference) timed on this host on a bounded sample.
+Rank 0 prints ONE JSON line.
+* `roofline` is for the dominant kernel (the fused Lanczos SpMV, `k_lz_spmv_x`): algorithmic bytes of its
+  launches / their summed duration, measured live with HIP start/stop events on every dispatch of the
+  library's stream.  Two regimes are measured and both are reported: `frac_solo` (one batched call alone on
+  the device) and `frac_overlapped` (the `--in-flight` host threads in flight together, i.e. the regime
+  `value` is quoted in); `frac` = the overlapped one.  `frac_aggregate` = all SpMV bytes of a step / the
+  step's wall time.  The rocprofv3 summaries of both regimes are tracked under `profiles/`.
+* `cpu_baseline` is the oracle (NumPy / SciPy restatement, scipy eigsh shift-invert as the reference):
+  `value` = the MEASURED single-process run on the full 200k chunk (cached in `profiles/`, it takes hours),
+  `pool` = a process pool on this host's cores over 20k-26k-point chunks, timed now.
+* `value_host_inputs` = the same loop with the inputs in pinned host memory (the library copies them on
+  the context's stream); `value` has them resident in HBM.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -37,6 +48,8 @@ sys.path.insert(0, ROOT)
 N_POINTS = 200_000
 CFG = dict(alpha=1.0, theta=0.5, gamma=0.0, T=0.03)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+CPU_200K_CACHE = os.path.join(ROOT, "profiles", "r02_cpu_oracle_200k.json")
+PMC_TRAFFIC = [os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"), os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")]
 
 
 def spmv_bytes(rows: int, nnz: int, launches: int) -> float:
@@ -49,40 +62,190 @@ def spmv_bytes(rows: int, nnz: int, launches: int) -> float:
 
 
 def pmc_traffic(batch: int):
-    """HBM-side bytes per SpMV launch from the committed PMC passes (`profiles/r01_pmc_traffic.json`:
-    rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of the same batched call, corrected
-    as MI355X_MICROARCH.md prescribes).  Counters cannot be read inside this process, so the number is
-    only reported when it was measured for the same chunks-per-batch; otherwise null."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            r = json.load(f)
-    except (OSError, ValueError):
-        return None, None
-    if f" {batch} 1" not in r.get("command", ""):
-        return None, None
-    return r.get("traffic_bytes_per_launch"), "profiles/r01_pmc_traffic_summary.txt"
+    """HBM-side bytes per SpMV launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and --pmc
+    WRITE_SIZE in separate runs of the same batched call, corrected as MI355X_MICROARCH.md prescribes).
+    Counters cannot be read inside this process, so the number is only reported when it was measured for
+    the same chunks-per-batch; otherwise null."""
+    for path in PMC_TRAFFIC:
+        try:
+            with open(path) as f:
+                r = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if f" {batch} 1" not in r.get("command", ""):
+            continue
+        return r.get("traffic_bytes_per_launch"), os.path.relpath(path, ROOT)
+    return None, None
 
 
-def cpu_baseline(seconds_budget: float = 30.0):
-    """Oracle on a bounded sample: one 20 000-point chunk of the same generator and config."""
+# ----------------------------------------------------------------------------- CPU baseline
+def _cpu_pool_worker(job):
+    """One oracle run in a pool worker (1 BLAS thread): returns (n, seconds, groups)."""
+    n, seed = job
+    os.environ["OMP_NUM_THREADS"] = "1"
+    os.environ["OPENBLAS_NUM_THREADS"] = "1"
     from autoinst_amd import synth
     from oracle import ncuts_ref
-    n = 20_000
-    ch = synth.synthetic_chunk(n, seed=0, tarl=True)
+    ch = synth.synthetic_chunk(n, seed=seed, tarl=True)
     t0 = time.perf_counter()
     groups = ncuts_ref.ncuts(ch["points"], ch["tarl"], alpha=CFG["alpha"], theta=CFG["theta"], gamma=CFG["gamma"],
                              T=CFG["T"], fast=True)
-    dt = time.perf_counter() - t0
-    # linear scaling in points flatters the CPU (eigsh grows faster than N: BASELINE.md section 2)
-    return {
-        "value": (n / dt) / N_POINTS,
-        "unit": "chunks/sec",
-        "cores": 1,
-        "kind": "port",
-        "sample": f"oracle/ncuts_ref.ncuts (cKDTree affinity + scipy eigsh sigma=1e-10 recursion) on one {n}-point "
-                  f"TARL+Spatial chunk: {dt:.1f} s, {len(groups)} groups; scaled linearly in points to a {N_POINTS}-point chunk",
+    return n, time.perf_counter() - t0, len(groups)
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(workers: int | None = None):
+    """The oracle beside the GPU number.
+
+    (i) `value`: the single-process oracle on the real 200k chunk, measured once in the build container by
+    `oracle/gen_fullsize.py` and cached (`profiles/r02_cpu_oracle_200k.json`; it takes hours, which a bench run
+    cannot afford).  (ii) `pool`: a process pool of this host's cores (1 BLAS thread each, one chunk of
+    20k-26k points -- the real chunk-size range -- per worker), timed now, ~30 s.
+    """
+    import multiprocessing as mp
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    if workers is None:
+        workers = int(os.environ.get("AI_BENCH_CPU_WORKERS", min(avail, 16)))  # a 1-GPU box's CPU share is 16 cores
+    workers = max(1, workers)
+    sizes = [int(x) for x in np.linspace(20_000, 26_000, workers)]
+    jobs = [(n, i) for i, n in enumerate(sizes)]
+    ctx = mp.get_context("spawn")   # fresh interpreters: nothing of this process's HIP state is inherited
+    t0 = time.perf_counter()
+    with ctx.Pool(workers) as pool:
+        res = pool.map(_cpu_pool_worker, jobs, chunksize=1)
+    wall = time.perf_counter() - t0
+    pts = sum(r[0] for r in res)
+    pool_info = {
+        "cores": workers, "host_cores_available": avail, "cpu_model": _cpu_model(),
+        "chunks": len(res), "points": pts, "wall_seconds": wall,
+        "chunks_per_sec_small": len(res) / wall,            # chunks of 20k-26k points per second, all workers
+        "points_per_sec": pts / wall,
+        "per_chunk_seconds_min_max": [min(r[1] for r in res), max(r[1] for r in res)],
+        "sample": f"{workers} workers x 1 chunk of {sizes[0]}-{sizes[-1]} points (seeds 0..{workers - 1}), oracle/ncuts_ref.ncuts, 1 BLAS thread each",
     }
+    out = {"unit": "chunks/sec", "kind": "port", "pool": pool_info}
+    try:
+        with open(CPU_200K_CACHE) as f:
+            c = json.load(f)
+        sec = float(c["affinity_seconds"]) + float(c["normalized_cut_seconds"])
+        out.update({
+            "value": 1.0 / sec, "cores": 1, "measured": True,
+            "sample": f"oracle/gen_fullsize.py on the full {c['n']}-point TARL+Spatial chunk (seed {c['seed']}), single process, "
+                      f"measured {sec:.0f} s ({c['eigsh_calls']} eigsh calls, {c['groups']} groups) on {c['cpu_model']} "
+                      f"({c['nproc']} cores, {c.get('concurrent_jobs', 1)} such jobs running side by side); cached in "
+                      f"{os.path.relpath(CPU_200K_CACHE, ROOT)}",
+        })
+    except (OSError, ValueError, KeyError):
+        # no cached full-size run: fall back to the pool's point rate, flagged as an extrapolation
+        out.update({"value": pool_info["points_per_sec"] / N_POINTS, "cores": workers, "measured": False, "extrapolated": True,
+                    "sample": pool_info["sample"] + f"; points/s scaled linearly to {N_POINTS}-point chunks (flatters the CPU)"})
+    return out
+
+
+# ----------------------------------------------------------------------------- self-launch
+def _free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n: int, argv) -> int:
+    """Start `n` ranks of this script as child processes (one per GPU) and relay rank 0's output.
+
+    Runs before torch is imported: the parent never touches HIP, it only waits.  If a rank exits non-zero
+    the others are terminated (by their PIDs) and the code is passed on.
+    """
+    port = int(os.environ.get("MASTER_PORT", "0")) or _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    code = 0
+    try:
+        while True:
+            rcs = [p.poll() for p in procs]
+            bad = [rc for rc in rcs if rc not in (None, 0)]
+            if bad:
+                code = bad[0]
+                break
+            if all(rc == 0 for rc in rcs):
+                break
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    reader.join(timeout=10)
+    out0 = b"".join(c for c in chunks if c)
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    return code
+
+
+# ----------------------------------------------------------------------------- dry run (CPU, gloo)
+def dry_run(args, world, rank):
+    """The multi-rank plumbing without a GPU: LPT deal of an uneven chunk list, per-step gather of label
+    arrays to rank 0 over `gloo`, barrier + max-over-ranks timing, one JSON line.  Computes nothing."""
+    import torch
+    import torch.distributed as dist
+    from autoinst_amd import sharding
+    if world > 1:
+        dist.init_process_group("gloo")
+    rng = np.random.default_rng(0)
+    nchunks = world * args.in_flight * args.batch
+    sizes = np.exp(rng.uniform(np.log(3_000), np.log(30_000), nchunks)).astype(int).tolist()   # cfg3's chunk-size mix
+    mine = sharding.lpt_assign(sizes, world)[rank]
+
+    def step():
+        local = {c: (np.arange(sizes[c], dtype=np.int32) % 7) for c in mine}
+        return sharding.gather_labels(local, device=torch.device("cpu")) if world > 1 else local
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        merged = step()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        assert merged is not None and sorted(merged) == list(range(nchunks)) and all(merged[c].shape[0] == sizes[c] for c in merged)
+        print(json.dumps({"metric": "dry run: chunk deal + label gather only (no compute)", "dry": True, "value": nchunks * args.steps / elapsed,
+                          "unit": "chunks/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "int32", "data": "synthetic", "rccl_ranks": world, "backend": "gloo" if world > 1 else "none",
+                          "config": {"workload": "label arrays of an uneven chunk list, LPT-dealt", "chunks_per_step": nchunks}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -93,22 +256,32 @@ def main():
     ap.add_argument("--in-flight", type=int, default=4, help="host threads (contexts) per GPU")
     ap.add_argument("--batch", type=int, default=6, help="chunks per batched call (root segments of one frontier)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-inputs", action="store_true", help="skip the pinned-host-input leg (value_host_inputs)")
+    ap.add_argument("--dry", action="store_true", help="CPU-only rehearsal of the multi-rank plumbing (gloo), no compute")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # nothing GPU-related has been imported yet: the ranks are fresh child processes
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"WORLD_SIZE = {world} but --gpus {args.gpus}: launch one rank per GPU")
+    if args.dry:
+        return dry_run(args, world, rank)
+
+    import torch
+    import torch.distributed as dist
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        import datetime
+        # a rank that dies leaves the others in a collective: the timeout turns that into a failure
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=600))
 
     from autoinst_amd import ncuts_api as api
     from autoinst_amd import sharding, synth
@@ -117,18 +290,28 @@ def main():
     B = max(1, args.batch)       # chunks per ai_ncut_batch call: root segments of one frontier
     dev = torch.device("cuda", local_rank)
     ctxs = [api.Context(local_rank) for _ in range(K)]
-    data = []
-    # K*B different chunks (seeds 0..K*B-1), all resident in HBM.  Every rank works on the SAME set, so
-    # the per-GPU work is exactly fixed as N grows (weak scaling); one chunk costs 26-59 ms depending
-    # on its seed, and a real map's spread is what sharding.lpt_assign balances.
+    # The world's chunk list (world*K*B chunks of N_POINTS points) is dealt to the ranks by the LPT rule the
+    # map driver uses; chunk c's input is the synthetic chunk of seed c mod K*B, so every rank holds the same
+    # K*B different inputs resident in HBM and the per-GPU work is exactly fixed as N grows (weak scaling;
+    # one chunk costs 26-59 ms depending on its seed).
+    my_chunks = sharding.lpt_assign([N_POINTS] * (world * K * B), world)[rank]
+    assert len(my_chunks) == K * B
+    data, host = [], []
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=4) as gen:   # set-up only: ~2 s of NumPy per chunk
-        for ch in gen.map(lambda i: synth.synthetic_chunk(N_POINTS, seed=i, tarl=True), range(K * B)):
+        for ch in gen.map(lambda c: synth.synthetic_chunk(N_POINTS, seed=c % (K * B), tarl=True), my_chunks):
             data.append((torch.from_numpy(ch["points"]).to(dev), torch.from_numpy(ch["tarl"]).to(dev)))
+            if not args.no_host_inputs:
+                host.append((torch.from_numpy(ch["points"]).pin_memory(), torch.from_numpy(ch["tarl"]).pin_memory()))
     torch.cuda.synchronize()
 
-    def one_batch(k, profile=False, only_first=False):
-        mine = data[k * B:(k + 1) * B][: 1 if only_first else B]
+    def one_batch(k, profile=False, only_first=False, from_host=False):
+        sl = slice(k * B, (k + 1) * B)
+        if from_host:
+            mine = [(p.numpy(), f.numpy()) for p, f in host[sl]]
+        else:
+            mine = data[sl]
+        mine = mine[: 1 if only_first else B]
         graphs = [api.build_affinity(p, f, alpha=CFG["alpha"], theta=CFG["theta"], gamma=CFG["gamma"], ctx=ctxs[k]) for p, f in mine]
         try:
             if len(graphs) == 1:
@@ -144,18 +327,19 @@ def main():
 
     import queue
     import threading
-    jobs = [queue.Queue() for _ in range(K)]   # per worker: number of batches to run (None = exit)
+    jobs = [queue.Queue() for _ in range(K)]   # per worker: (number of batches, kwargs) (None = exit)
     qs = [queue.Queue() for _ in range(K)]     # per worker: results, one per batch
 
     def worker(k):
         # the K host threads live for the whole run (warm-up, timed steps, latency and profile passes)
         while True:
-            n = jobs[k].get()
-            if n is None:
+            job = jobs[k].get()
+            if job is None:
                 return
+            n, kw = job
             for _ in range(n):
                 try:
-                    qs[k].put(one_batch(k))
+                    qs[k].put(one_batch(k, **kw))
                 except BaseException as e:  # surface the failure in the consuming thread
                     qs[k].put(e)
                     break
@@ -164,20 +348,25 @@ def main():
     for t in workers:
         t.start()
 
-    def run_steps(nsteps):
+    def run_steps(nsteps, **kw):
         """`nsteps` steps: every host thread pushes `nsteps` batches back to back (the library calls release
         the GIL, so the K batches really are in flight together, and a thread does not wait for the others
         between steps); this thread takes each step's K results as they complete and (N > 1) gathers that
         step's label arrays to rank 0.  Returns the last step's results."""
         for k in range(K):
-            jobs[k].put(nsteps)
+            jobs[k].put((nsteps, kw))
         last = None
         for _ in range(nsteps):
             res = [q.get() for q in qs]
             for r in res:
                 if isinstance(r, BaseException):
+                    if world > 1:
+                        # the other ranks are (or will be) inside a collective: leave so that the launcher ends them
+                        sys.stderr.write(f"rank {rank}: {type(r).__name__}: {r}\n")
+                        sys.stderr.flush()
+                        os._exit(1)
                     raise r
-            local = {(rank * K + k) * B + b: res[k][0][b] for k in range(K) for b in range(B)}
+            local = {my_chunks[k * B + b]: res[k][0][b] for k in range(K) for b in range(B)}
             merged = sharding.gather_labels(local, device=dev) if world > 1 else local
             last = (res, merged)
         return last
@@ -187,30 +376,52 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(nsteps, **kw):
+        barrier()
+        t0 = time.perf_counter()
+        last = run_steps(nsteps, **kw)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, last
+
     if args.warmup > 0:
         run_steps(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    last = run_steps(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, last = timed(args.steps)
     res, merged = last
     nnz = res[0][3]
     stb = res[0][2]
 
-    # one chunk alone (latency and per-chunk counters), then a profiled repeat of one batched call:
-    # HIP start/stop events on every SpMV dispatch
+    # ---- the same loop with the inputs in pinned host memory (the library copies them on the context's stream)
+    host_steps, elapsed_host = 0, None
+    if host:
+        host_steps = max(2, args.steps // 4)
+        run_steps(1, from_host=True)
+        elapsed_host, _ = timed(host_steps, from_host=True)
+
+    # ---- roofline of the SpMV kernel, overlapped regime: the K host threads each run one batched call with HIP
+    # start/stop events on every SpMV dispatch, in flight together exactly as in the timed region
+    t_ov0 = time.perf_counter()
+    res_ov, _ = run_steps(1, profile=True)
+    t_ov = time.perf_counter() - t_ov0
+    ov = {"launches": 0, "bytes": 0.0, "ms": 0.0}
+    for k in range(K):
+        s = res_ov[k][2]
+        ov["launches"] += int(s["lanczos_steps"])
+        ov["bytes"] += spmv_bytes(int(s["spmv_rows"]), int(s["spmv_nnz"]), int(s["lanczos_steps"]))
+        ov["ms"] += s["ms_spmv"]
+
+    # ---- one chunk alone (latency and per-chunk counters), then the solo regime: ONE batched call alone on the device
     one_batch(0, only_first=True)
     t1 = time.perf_counter()
     for _ in range(3):
         labs1, ngs1, st, _ = one_batch(0, only_first=True)
     latency_ms = 1e3 * (time.perf_counter() - t1) / 3
     ng = ngs1[0]
-    _, _, stp, _ = one_batch(0, profile=True)   # the batched call as timed above, SpMV dispatches bracketed
+    _, _, stp, _ = one_batch(0, profile=True)
     barrier()
     for k in range(K):
         jobs[k].put(None)
@@ -219,10 +430,13 @@ def main():
 
     free_b, total_b = torch.cuda.mem_get_info(dev)
     if rank == 0:
-        assert merged is not None and len(merged) == world * K * B and all(v.shape[0] == N_POINTS for v in merged.values())
+        assert merged is not None and sorted(merged) == list(range(world * K * B)) and all(v.shape[0] == N_POINTS for v in merged.values())
         launches = int(stp["lanczos_steps"])
         b = spmv_bytes(int(stp["spmv_rows"]), int(stp["spmv_nnz"]), launches)
-        ach = b / (stp["ms_spmv"] * 1e-3) / 1e9 if stp["ms_spmv"] > 0 else 0.0
+        ach_solo = b / (stp["ms_spmv"] * 1e-3) / 1e9 if stp["ms_spmv"] > 0 else 0.0
+        ach_ov = ov["bytes"] / (ov["ms"] * 1e-3) / 1e9 if ov["ms"] > 0 else 0.0
+        ms_step = 1e3 * elapsed / args.steps
+        ach_agg = ov["bytes"] / (ms_step * 1e-3) / 1e9   # every SpMV byte of one step / the step's wall time
         traffic, traffic_src = pmc_traffic(B)
         out = {
             "metric": "chunks/sec (200k-pt TARL+Spatial NCuts chunk: affinity build + recursive normalized cut)",
@@ -231,16 +445,21 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step": ms_step,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "backend": dist.get_backend() if world > 1 else "none",
             "config": {"workload": "configs[1]: single 200k-point surface chunk, TARL(96-d)+Spatial affinities, "
                                    f"alpha=1 theta=0.5 T=0.03; per GPU per step {K} host threads x {B} chunks batched into one frontier",
                        "n_points": N_POINTS, "nnz": int(nnz), "chunks_per_step": world * K * B, "threads_per_gpu": K, "chunks_per_batch": B,
                        "parallelism": f"chunk-dp{world}"},
+            "value_host_inputs": (world * K * B * host_steps / elapsed_host) if elapsed_host else None,
+            "host_inputs_note": "same loop, points + features in pinned host memory (159 MB per chunk), copied by the library on the context's stream"
+                                if elapsed_host else None,
             "hbm_in_use_gb": (total_b - free_b) / 1e9,   # inputs + K workspaces (arena, cached graph buffers) + torch
             "single_chunk_latency_ms": latency_ms,
             "batch_ncut_ms": stb["ms_total"],
@@ -257,15 +476,22 @@ def main():
             "roofline": {
                 "kernel": "k_lz_spmv_x",
                 "bound": "hbm",
-                "achieved": ach,
+                "achieved": ach_ov,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBPS,
+                "frac": ach_ov / HBM_PEAK_GBPS,
+                "frac_is": f"overlapped: {K} host threads in flight, as in the timed region",
+                "frac_overlapped": ach_ov / HBM_PEAK_GBPS,
+                "frac_solo": ach_solo / HBM_PEAK_GBPS,
+                "frac_aggregate": ach_agg / HBM_PEAK_GBPS,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
-                "launches": launches,
-                "avg_launch_us": 1e3 * stp["ms_spmv"] / max(launches, 1),
-                "bytes_per_launch_avg": b / max(launches, 1),
+                "overlapped": {"launches": ov["launches"], "avg_launch_us": 1e3 * ov["ms"] / max(ov["launches"], 1),
+                               "bytes_per_launch_avg": ov["bytes"] / max(ov["launches"], 1), "achieved_gbps": ach_ov,
+                               "step_wall_ms_with_events": 1e3 * t_ov},
+                "solo": {"launches": launches, "avg_launch_us": 1e3 * stp["ms_spmv"] / max(launches, 1),
+                         "bytes_per_launch_avg": b / max(launches, 1), "achieved_gbps": ach_solo},
+                "aggregate_gbps": ach_agg,
             },
         }
         if not args.no_cpu_baseline:
