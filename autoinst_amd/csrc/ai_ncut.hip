@@ -9,8 +9,13 @@
 //   * rows of a segment are contiguous ("compact order"); after a split the rows are stably
 //     partitioned (mask side first) and the CSR is rebuilt without the cut edges, so the
 //     left-to-right order of leaf segments is the reference's emission order;
-//   * a DISCONNECTED segment (union-find over the CSR) gets an explicit null-space vector of L,
-//     z = D^1/2 (1_A / vol_A - 1_B / vol_B): SciPy returns an arbitrary null-space vector there;
+//   * a DISCONNECTED segment (union-find over the CSR) is split into its connected components in ONE step.
+//     That is what the reference's recursion makes of it: eigsh(sigma=1e-10) returns the indicator vector
+//     D^1/2 1_C of ONE component there (every component has its own computed "zero" eigenvalue of size ~1e-17
+//     and shift-invert resolves them), the sweep cuts exactly that component off at cost 0, and the recursion
+//     goes on with the remainder -- components are peeled off one at a time.  (The reference stops peeling when
+//     the remainder falls to <= 1 % of the chunk; which components are left in that one remainder is decided by
+//     round-off inside SuperLU, so it cannot be reproduced: here every component continues on its own.);
 //   * a CONNECTED segment is solved by Lanczos on M = D^-1/2 W D^-1/2 = I - L without
 //     re-orthogonalisation, every Lanczos vector kept in HBM, the known top eigenvector
 //     u1 = D^1/2 1 / sqrt(vol) projected out of each new vector; the top Ritz pair of T_m is the
@@ -27,6 +32,7 @@
 #include <set>
 
 #include <hip/hip_ext.h>
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include "ai_common.h"
 
@@ -1088,10 +1094,12 @@ __device__ __forceinline__ void mm_merge(MinMaxPart& r, const MinMaxPart& q) {
   }
 }
 
-__global__ __launch_bounds__(AI_BLOCK) void k_minmax(const Task* __restrict__ ctasks, const double* __restrict__ ev,
-                                                     const int32_t* __restrict__ orig, MinMaxPart* __restrict__ part) {
+__global__ __launch_bounds__(AI_BLOCK) void k_minmax(const Task* __restrict__ ctasks, const int32_t* __restrict__ mode,
+                                                     const double* __restrict__ ev, const int32_t* __restrict__ orig,
+                                                     MinMaxPart* __restrict__ part) {
   __shared__ MinMaxPart sm[AI_BLOCK / 64];
   const Task tk = ctasks[blockIdx.x];
+  if (mode && mode[tk.z] != 0) return;  // a disconnected segment has no eigenvector: it is split by components
   MinMaxPart r;
   r.mn = 1e300;
   r.mx = -1e300;
@@ -1133,10 +1141,16 @@ __global__ __launch_bounds__(AI_BLOCK) void k_minmax(const Task* __restrict__ ct
 // Per segment: unit norm + sign convention folded into one scale; np.allclose(mn, mx) test
 // (normalized_cut.py:22); thresholds t_k = k * step + mn, step = (mx - mn) / 10, exactly as
 // np.linspace(mn, mx, 10, endpoint=False) computes them (:28).
-__global__ void k_minmax_final(const int32_t* __restrict__ ctask0, const MinMaxPart* __restrict__ part, int S, int raw,
-                               double* __restrict__ scale, int32_t* __restrict__ nosplit, double* __restrict__ thr) {
+__global__ void k_minmax_final(const int32_t* __restrict__ ctask0, const int32_t* __restrict__ mode,
+                               const MinMaxPart* __restrict__ part, int S, int raw, double* __restrict__ scale,
+                               int32_t* __restrict__ nosplit, double* __restrict__ thr) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= S) return;
+  if (mode && mode[s] != 0) {
+    scale[s] = 1.0;
+    nosplit[s] = 1;
+    return;
+  }
   MinMaxPart r = part[ctask0[s]];
   for (int t = ctask0[s] + 1; t < ctask0[s + 1]; ++t) mm_merge(r, part[t]);
   double sc = 1.0;
@@ -1154,11 +1168,12 @@ __global__ void k_minmax_final(const int32_t* __restrict__ ctask0, const MinMaxP
 }
 
 // bin_i = number of thresholds strictly below ev_i: mask_k(i) = (ev_i > t_k) = (k < bin_i)
-__global__ __launch_bounds__(AI_BLOCK) void k_bin(const Task* __restrict__ ctasks, const double* __restrict__ scale,
-                                                  const double* __restrict__ thr, const double* __restrict__ ev,
-                                                  uint8_t* __restrict__ bin) {
+__global__ __launch_bounds__(AI_BLOCK) void k_bin(const Task* __restrict__ ctasks, const int32_t* __restrict__ nosplit,
+                                                  const double* __restrict__ scale, const double* __restrict__ thr,
+                                                  const double* __restrict__ ev, uint8_t* __restrict__ bin) {
   const Task tk = ctasks[blockIdx.x];
   const int s = tk.z;
+  if (nosplit[s]) return;  // no threshold will be applied to this segment (k_split_flags looks at split[] first)
   const double sc = scale[s];
   double th[AI_NUM_CUTS];
 #pragma unroll
@@ -1322,9 +1337,10 @@ __global__ __launch_bounds__(AI_BLOCK) void k_partition(const Task* __restrict__
                                                         const int32_t* __restrict__ childB, const int32_t* __restrict__ flag,
                                                         const int32_t* __restrict__ fscan, const int32_t* __restrict__ orig,
                                                         int32_t* __restrict__ final_order, int32_t* __restrict__ map,
-                                                        int32_t* __restrict__ orig_next) {
+                                                        int32_t* __restrict__ orig_next, const int32_t* __restrict__ multi) {
   const Task tk = ctasks[blockIdx.x];
   const int s = tk.z;
+  if (multi[s]) return;  // split by components: k_partition_multi
   const int s0 = seg_start[s], g0 = seg_gstart[s], nt = split[s] ? ntrue[s] : 0;
   const int cA = childA[s], cB = childB[s];
   const int f0 = fscan[s0];
@@ -1341,6 +1357,61 @@ __global__ __launch_bounds__(AI_BLOCK) void k_partition(const Task* __restrict__
     } else {
       if (cB >= 0) dst = cB + rf;
     }
+    map[row] = dst;
+    if (dst >= 0) orig_next[dst] = id;
+  }
+}
+
+
+// ---- a disconnected segment is split into ALL its connected components at once (see the file header).
+// Component = union-find root = its first row; components keep the order of their first rows, rows keep
+// their order inside a component: a stable sort of the rows by root id (segments stay where they are,
+// because a root lies inside its segment's row range).
+
+// rc[row] = 1 for the roots of the segments that are split by components
+__global__ __launch_bounds__(AI_BLOCK) void k_comp_rootflag(const Task* __restrict__ ctasks, const int32_t* __restrict__ multi,
+                                                            const int32_t* __restrict__ parent, int32_t* __restrict__ rc) {
+  const Task tk = ctasks[blockIdx.x];
+  const int m = multi[tk.z];
+  for (int row = tk.x + threadIdx.x; row < tk.y; row += AI_BLOCK) rc[row] = (m && parent[row] == row) ? 1 : 0;
+}
+
+// component table in row order: (root row, rows of the component)
+__global__ __launch_bounds__(AI_BLOCK) void k_comp_table(const Task* __restrict__ ctasks, const int32_t* __restrict__ multi,
+                                                         const int32_t* __restrict__ parent, const int32_t* __restrict__ rootord,
+                                                         const int32_t* __restrict__ rcnt, int32_t* __restrict__ troot,
+                                                         int32_t* __restrict__ tsize) {
+  const Task tk = ctasks[blockIdx.x];
+  if (!multi[tk.z]) return;
+  for (int row = tk.x + threadIdx.x; row < tk.y; row += AI_BLOCK)
+    if (parent[row] == row) {
+      const int o = rootord[row];
+      troot[o] = row;
+      tsize[o] = rcnt[row];
+    }
+}
+
+// p = position of a row after the stable sort by root.  The row goes to position p of its parent's range in the
+// final ordering and, if its component continues (cbase >= 0), to row cbase + (rank inside the component) of
+// the next level's compact order.
+__global__ __launch_bounds__(AI_BLOCK) void k_partition_multi(const Task* __restrict__ ctasks, const int32_t* __restrict__ multi,
+                                                              const int32_t* __restrict__ seg_start, const int32_t* __restrict__ seg_gstart,
+                                                              const int32_t* __restrict__ sorted_rows, const int32_t* __restrict__ parent,
+                                                              const int32_t* __restrict__ rootord, const int32_t* __restrict__ cpos,
+                                                              const int32_t* __restrict__ cbase, const int32_t* __restrict__ orig,
+                                                              int32_t* __restrict__ final_order, int32_t* __restrict__ map,
+                                                              int32_t* __restrict__ orig_next) {
+  const Task tk = ctasks[blockIdx.x];
+  const int s = tk.z;
+  if (!multi[s]) return;
+  const int s0 = seg_start[s], g0 = seg_gstart[s];
+  for (int p = tk.x + threadIdx.x; p < tk.y; p += AI_BLOCK) {
+    const int row = sorted_rows[p];
+    const int o = rootord[parent[row]];
+    const int32_t id = orig[row];
+    final_order[g0 + (p - s0)] = id;
+    const int base = cbase[o];
+    const int32_t dst = (base >= 0) ? base + (p - cpos[o]) : -1;
     map[row] = dst;
     if (dst >= 0) orig_next[dst] = id;
   }
@@ -1770,7 +1841,9 @@ class Solver {
   TaskList lzf, lzc;      // rows of the Lanczos-mode segments only (grids of the step kernels)
   std::vector<TaskRange> h_cranges, h_segrange;
   Ptr<TaskRange> cranges, segrange;
-  DevBuf<char> blobA, blobB, blobC, resblob, lzres;
+  DevBuf<char> blobA, blobB, blobC, blobD, resblob, lzres;
+  DevBuf<int32_t> t_root, t_size;  // component table of the disconnected segments
+  DevBuf<uint8_t> sorttmp;
   size_t rescap = 0;
   std::vector<int32_t> h_seg_start;
   Ptr<int32_t> seg_start, factive, cactive;
@@ -1778,7 +1851,7 @@ class Solver {
   DevBuf<double2> pB[2];
   DevBuf<MinMaxPart> pmm;
   // per-segment device arrays
-  Ptr<int32_t> s_mode, s_needcc, s_gstart, s_childA, s_childB;  // uploaded per level (blobs)
+  Ptr<int32_t> s_mode, s_needcc, s_gstart, s_childA, s_childB, s_multi, c_pos, c_base;  // uploaded per level (blobs)
   Ptr<int32_t> s_split, s_ntrue, s_frozen, s_m;                  // downloaded per level (resblob / lzres)
   Ptr<double> s_mcut, s_resid, s_theta;
   DevBuf<int32_t> s_ncomp, s_nosplit, s_kstar, slots;
@@ -2499,14 +2572,16 @@ class Solver {
   }
 
   // min/max, bins, 10 costs, decision -> host vectors (raw = 1: ev used as given)
-  int sweep(double T, int raw, std::vector<int32_t>& h_split, std::vector<int32_t>& h_ntrue, std::vector<double>& h_mcut) {
+  // skip_disconnected: segments of mode 1 have no eigenvector (they are split by components) and are left out
+  int sweep(double T, int raw, bool skip_disconnected, std::vector<int32_t>& h_split, std::vector<int32_t>& h_ntrue, std::vector<double>& h_mcut) {
     const int S_ = S();
+    const int32_t* md = skip_disconnected ? (const int32_t*)s_mode.p : nullptr;
     AI_HIP(hipEventRecord(ctx->ev[2], st));
-    hipLaunchKernelGGL(k_minmax, dim3(coarse.n), dim3(AI_BLOCK), 0, st, coarse.d.p, ev.p, orig, pmm.p);
+    hipLaunchKernelGGL(k_minmax, dim3(coarse.n), dim3(AI_BLOCK), 0, st, coarse.d.p, md, ev.p, orig, pmm.p);
     AI_KERNEL_CHECK();
-    hipLaunchKernelGGL(k_minmax_final, dim3((S_ + 63) / 64), dim3(64), 0, st, coarse.d_seg0.p, pmm.p, S_, raw, s_scale.p, s_nosplit.p, s_thr.p);
+    hipLaunchKernelGGL(k_minmax_final, dim3((S_ + 63) / 64), dim3(64), 0, st, coarse.d_seg0.p, md, pmm.p, S_, raw, s_scale.p, s_nosplit.p, s_thr.p);
     AI_KERNEL_CHECK();
-    hipLaunchKernelGGL(k_bin, dim3(coarse.n), dim3(AI_BLOCK), 0, st, coarse.d.p, s_scale.p, s_thr.p, ev.p, bin.p);
+    hipLaunchKernelGGL(k_bin, dim3(coarse.n), dim3(AI_BLOCK), 0, st, coarse.d.p, s_nosplit.p, s_scale.p, s_thr.p, ev.p, bin.p);
     AI_KERNEL_CHECK();
     hipLaunchKernelGGL(k_sweep, dim3(fine.n), dim3(AI_BLOCK), 0, st, fine.d.p, s_nosplit.p, rowptr, col, wraw, deg.p, bin.p, psweep.p);
     AI_KERNEL_CHECK();
@@ -2598,22 +2673,91 @@ static int ncut_impl(ai_ctx* ctx, const ai_csr* csr, int nchunks, const int64_t*
       pending_rebuild = false;
     }
     AI_HIP(hipEventRecord(ctx->ev[5], st));
-    AI_TRY(S.null_vectors());
     AI_TRY(S.lanczos(nullptr, nullptr, nullptr));
-    AI_TRY(S.sweep(T, 0, h_split, h_ntrue, h_mcut));
+    AI_TRY(S.sweep(T, 0, true, h_split, h_ntrue, h_mcut));
     {
       float ms1 = 0.f;
       AI_HIP(hipEventElapsedTime(&ms1, ctx->ev[4], ctx->ev[5]));
       S.stats.ms_rebuild += ms1;
     }
-    // ---- children (deeper calls use split_lim = 0.01: normalized_cut.py:57-58 rely on the default)
     const int S_ = S.S();
+    // ---- disconnected segments: the component table (root row, rows) in row order.  The cut between whole
+    // components costs exactly 0, and the reference splits iff mcut < T (normalized_cut.py:56): nothing for T <= 0.
+    std::vector<int32_t> multi(S_ + 1, 0);
+    bool any_multi = false;
+    for (int s = 0; s < S_; ++s) {
+      multi[s] = (S.segs[s].mode == 1 && T > 0.0) ? 1 : 0;
+      any_multi |= (multi[s] != 0);
+      S.stats.null_solves += (S.segs[s].mode == 1);
+    }
+    AI_HIP(hipEventRecord(ctx->ev[6], st));
+    std::vector<int32_t> t_root, t_size;
+    if (any_multi) {
+      Pack pk(ctx->stage + 3 * (AI_STAGE_BYTES / 4), AI_STAGE_BYTES / 4);
+      pk.add(&S.s_multi.p, multi.data(), (size_t)S_ + 1);
+      AI_TRY(pk.flush(S.blobD, st));
+      AI_HIP(hipMemsetAsync(S.rcnt.p, 0, (size_t)S.na * sizeof(int32_t), st));
+      hipLaunchKernelGGL(k_null_rootcount, dim3(S.coarse.n), dim3(AI_BLOCK), 0, st, S.coarse.d.p, (const int32_t*)S.s_multi.p, (const int32_t*)S.parent,
+                         S.rcnt.p);
+      AI_KERNEL_CHECK();
+      hipLaunchKernelGGL(k_comp_rootflag, dim3(S.coarse.n), dim3(AI_BLOCK), 0, st, S.coarse.d.p, (const int32_t*)S.s_multi.p, (const int32_t*)S.parent,
+                         S.rc.p);
+      AI_KERNEL_CHECK();
+      AI_TRY(ai_exclusive_scan_i32(st, S.rc.p, S.ex.p, S.na, S.scantmp.p));  // ex[row] = ordinal of a root, ex[na] = components
+      int32_t ncomp_all = 0;
+      AI_HIP(hipMemcpyAsync(&ncomp_all, S.ex.p + S.na, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      AI_HIP(hipStreamSynchronize(st));
+      if (ncomp_all < 2 || ncomp_all > S.na) {
+        ai_set_error("internal: %d components in the disconnected segments of a level with %d rows", ncomp_all, S.na);
+        return AI_ERR_INTERNAL;
+      }
+      AI_TRY(S.t_root.ensure((size_t)ncomp_all));
+      AI_TRY(S.t_size.ensure((size_t)ncomp_all));
+      hipLaunchKernelGGL(k_comp_table, dim3(S.coarse.n), dim3(AI_BLOCK), 0, st, S.coarse.d.p, (const int32_t*)S.s_multi.p, (const int32_t*)S.parent,
+                         (const int32_t*)S.ex.p, (const int32_t*)S.rcnt.p, S.t_root.p, S.t_size.p);
+      AI_KERNEL_CHECK();
+      t_root.resize(ncomp_all);
+      t_size.resize(ncomp_all);
+      AI_HIP(hipMemcpyAsync(t_root.data(), S.t_root.p, (size_t)ncomp_all * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      AI_HIP(hipMemcpyAsync(t_size.data(), S.t_size.p, (size_t)ncomp_all * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      AI_HIP(hipStreamSynchronize(st));
+    }
+    // ---- children (deeper calls use split_lim = 0.01: normalized_cut.py:57-58 rely on the default)
     std::vector<SegHost> next;
     std::vector<int32_t> cA(S_, -1), cB(S_, -1);
+    std::vector<int32_t> c_pos(t_root.size(), 0), c_base(t_root.size(), -1);
     int cstart = 0;
     bool any_carry = false;
+    size_t ti = 0;  // next entry of the component table
     for (int s = 0; s < S_; ++s) {
       const SegHost& sg = S.segs[s];
+      if (multi[s]) {
+        // every connected component continues on its own, in the order of their first rows
+        int off = 0;
+        while (ti < t_root.size() && t_root[ti] < sg.start + sg.n) {
+          const int nc = t_size[ti];
+          if (t_root[ti] < sg.start || nc <= 0 || off + nc > sg.n) {
+            ai_set_error("internal: component table does not tile segment %d", s);
+            return AI_ERR_INTERNAL;
+          }
+          c_pos[ti] = sg.start + off;
+          if (eligible(nc, n_orig[sg.chunk], 0.01)) {
+            c_base[ti] = cstart;
+            next.push_back(SegHost{cstart, nc, sg.gstart + off, 0, 0, sg.chunk});  // connected: its labels are carried
+            cstart += nc;
+            any_carry = true;
+          } else {
+            leaf_starts.push_back(sg.gstart + off);
+          }
+          off += nc;
+          ++ti;
+        }
+        if (off != sg.n) {
+          ai_set_error("internal: components of segment %d cover %d of %d rows", s, off, sg.n);
+          return AI_ERR_INTERNAL;
+        }
+        continue;
+      }
       if (!h_split[s]) {
         leaf_starts.push_back(sg.gstart);
         continue;
@@ -2623,30 +2767,28 @@ static int ncut_impl(ai_ctx* ctx, const ai_csr* csr, int nchunks, const int64_t*
         ai_set_error("internal: split of segment %d produced an empty side (%d / %d)", s, na_, nb_);
         return AI_ERR_INTERNAL;
       }
-      // a null-vector cut of cost exactly 0 runs between whole components: their labels stay valid
-      const int carry = (sg.mode == 1 && h_mcut[s] == 0.0) ? 1 : 0;
       if (eligible(na_, n_orig[sg.chunk], 0.01)) {
         cA[s] = cstart;
-        next.push_back(SegHost{cstart, na_, sg.gstart, 0, carry ? 0 : 1, sg.chunk});
+        next.push_back(SegHost{cstart, na_, sg.gstart, 0, 1, sg.chunk});
         cstart += na_;
-        any_carry |= (carry != 0);
       } else {
         leaf_starts.push_back(sg.gstart);
       }
       if (eligible(nb_, n_orig[sg.chunk], 0.01)) {
         cB[s] = cstart;
-        next.push_back(SegHost{cstart, nb_, sg.gstart + na_, 0, carry ? 0 : 1, sg.chunk});
+        next.push_back(SegHost{cstart, nb_, sg.gstart + na_, 0, 1, sg.chunk});
         cstart += nb_;
-        any_carry |= (carry != 0);
       } else {
         leaf_starts.push_back(sg.gstart + na_);
       }
     }
-    AI_HIP(hipEventRecord(ctx->ev[6], st));
     {
       Pack pk(ctx->stage + 3 * (AI_STAGE_BYTES / 4), AI_STAGE_BYTES / 4);
       pk.add(&S.s_childA.p, cA.data(), (size_t)S_);
       pk.add(&S.s_childB.p, cB.data(), (size_t)S_);
+      pk.add(&S.s_multi.p, multi.data(), (size_t)S_ + 1);
+      pk.add(&S.c_pos.p, c_pos.data(), c_pos.size());
+      pk.add(&S.c_base.p, c_base.data(), c_base.size());
       AI_TRY(pk.flush(S.blobC, st));
     }
     hipLaunchKernelGGL(k_split_flags, dim3(S.coarse.n), dim3(AI_BLOCK), 0, st, S.coarse.d.p, S.s_split.p, S.s_kstar.p, S.bin.p, S.flag.p);
@@ -2654,8 +2796,25 @@ static int ncut_impl(ai_ctx* ctx, const ai_csr* csr, int nchunks, const int64_t*
     AI_TRY(ai_exclusive_scan_i32(st, S.flag.p, S.fscan.p, S.na, S.scantmp.p));
     const int pp = S.pp;
     hipLaunchKernelGGL(k_partition, dim3(S.coarse.n), dim3(AI_BLOCK), 0, st, S.coarse.d.p, S.seg_start.p, S.s_gstart.p, S.s_split.p, S.s_ntrue.p,
-                       S.s_childA.p, S.s_childB.p, S.flag.p, S.fscan.p, S.orig, S.final_order.p, S.map.p, S.b_orig[pp].p);
+                       S.s_childA.p, S.s_childB.p, S.flag.p, S.fscan.p, S.orig, S.final_order.p, S.map.p, S.b_orig[pp].p, (const int32_t*)S.s_multi.p);
     AI_KERNEL_CHECK();
+    if (any_multi) {
+      // stable sort of the level's rows by root id (rows of connected segments all carry their segment's first row)
+      int bits = 1;
+      while ((1ll << bits) < (long long)S.na) ++bits;
+      hipLaunchKernelGGL(k_iota, dim3((unsigned)((S.na + AI_BLOCK - 1) / AI_BLOCK)), dim3(AI_BLOCK), 0, st, S.rc.p, S.na);
+      AI_KERNEL_CHECK();
+      size_t tmp_bytes = 0;
+      AI_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const uint32_t*)S.parent, (uint32_t*)S.newcnt.p, (const int32_t*)S.rc.p, S.rcnt.p,
+                                       (size_t)S.na, 0, bits, st));
+      AI_TRY(S.sorttmp.ensure(tmp_bytes));
+      AI_HIP(rocprim::radix_sort_pairs((void*)S.sorttmp.p, tmp_bytes, (const uint32_t*)S.parent, (uint32_t*)S.newcnt.p, (const int32_t*)S.rc.p, S.rcnt.p,
+                                       (size_t)S.na, 0, bits, st));
+      hipLaunchKernelGGL(k_partition_multi, dim3(S.coarse.n), dim3(AI_BLOCK), 0, st, S.coarse.d.p, (const int32_t*)S.s_multi.p, S.seg_start.p,
+                         S.s_gstart.p, (const int32_t*)S.rcnt.p, (const int32_t*)S.parent, (const int32_t*)S.ex.p, (const int32_t*)S.c_pos.p,
+                         (const int32_t*)S.c_base.p, S.orig, S.final_order.p, S.map.p, S.b_orig[pp].p);
+      AI_KERNEL_CHECK();
+    }
     int32_t* parent_next = (S.parent == S.b_parent[0].p) ? S.b_parent[1].p : S.b_parent[0].p;
     if (cstart > 0) {
       const unsigned gr = (unsigned)((S.na + AI_BLOCK - 1) / AI_BLOCK);
@@ -2831,9 +2990,10 @@ extern "C" int ai_fiedler(ai_ctx* ctx, const ai_csr* csr, const ai_ncut_opts* op
   AI_TRY(S.lanczos(&theta, &it, &rs));
   hipStream_t st = ctx->stream;
   // unit norm + sign convention, then back to the caller's order
-  hipLaunchKernelGGL(k_minmax, dim3(S.coarse.n), dim3(AI_BLOCK), 0, st, S.coarse.d.p, S.ev.p, S.orig, S.pmm.p);
+  hipLaunchKernelGGL(k_minmax, dim3(S.coarse.n), dim3(AI_BLOCK), 0, st, S.coarse.d.p, (const int32_t*)nullptr, S.ev.p, S.orig, S.pmm.p);
   AI_KERNEL_CHECK();
-  hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(64), 0, st, S.coarse.d_seg0.p, S.pmm.p, 1, 0, S.s_scale.p, S.s_nosplit.p, S.s_thr.p);
+  hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(64), 0, st, S.coarse.d_seg0.p, (const int32_t*)nullptr, S.pmm.p, 1, 0, S.s_scale.p, S.s_nosplit.p,
+                     S.s_thr.p);
   AI_KERNEL_CHECK();
   double sc = 1.0;
   AI_HIP(hipMemcpyAsync(&sc, S.s_scale.p, sizeof(double), hipMemcpyDeviceToHost, st));
@@ -2867,7 +3027,7 @@ extern "C" int ai_sweep(ai_ctx* ctx, const ai_csr* csr, const double* ev, double
   AI_KERNEL_CHECK();
   std::vector<int32_t> sp, nt;
   std::vector<double> mcs;
-  AI_TRY(S.sweep(INFINITY, 1, sp, nt, mcs));
+  AI_TRY(S.sweep(INFINITY, 1, false, sp, nt, mcs));
   AI_HIP(hipMemcpyAsync(costs, S.s_costs.p, AI_NUM_CUTS * sizeof(double), hipMemcpyDeviceToHost, st));
   int32_t ks = 0;
   AI_HIP(hipMemcpyAsync(&ks, S.s_kstar.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));

@@ -129,6 +129,50 @@ def make_fixture(name, points, tarl, dino, cfg, ref_ncut, check_dense=True):
           f"disconnected_solves={walk['disconnected_solves']} fast_equal={fast_equal} eig={np.sort(eigvals)} mcut={mcut:.4g}")
 
 
+def make_cfg1_fixture(name, n, seed, extent, cfg, with_tarl):
+    """A fixture at configs[0]'s own size (N = 10k, extent 25 m): the IMPORTED reference
+    end to end (``normalized_cut.py:37-63``, dense ``D.todense()`` and all: ~2 min and a few GB here), the
+    restatement asserted equal to it, and the dense affinity lines (``ncuts_utils.py:60-67,135-156``) asserted
+    equal to the sparse restatement.  Stored: inputs, ground truth, the reference's labels and group sizes,
+    how many of its solves met a disconnected segment, and its scores."""
+    import time
+    points, gt = synth.surface_chunk(n, seed=seed, extent=extent)
+    tarl = synth.surrogate_features(gt, 96, seed) if with_tarl else None
+    alpha, theta, gamma, T = cfg["alpha"], cfg["theta"], cfg["gamma"], cfg["T"]
+    A = ncuts_ref.affinity_sparse(points, tarl, None, alpha=alpha, theta=theta, gamma=gamma)
+    Ad = ncuts_ref.affinity_dense(points, tarl, None, alpha=alpha, theta=theta, gamma=gamma)
+    keep, _ = ncuts_ref.remove_isolated_points(Ad)
+    assert keep.all()
+    Ad = sp.csr_matrix(Ad)
+    Ad.sort_indices()
+    assert np.array_equal(Ad.indptr, A.indptr) and np.array_equal(Ad.indices, A.indices), name
+    assert np.abs(Ad.data - A.data).max() <= 1e-15, name
+    del Ad
+    t0 = time.perf_counter()
+    groups_ref = _fresh("ref", A, n, T)
+    t_ref = time.perf_counter() - t0
+    groups_fast = _fresh("oracle_fast", A, n, T)
+    assert len(groups_ref) == len(groups_fast) and all(np.array_equal(a, b) for a, b in zip(groups_ref, groups_fast)), name
+    lab = ncuts_ref.groups_to_labels(groups_ref, n)
+    assert (lab >= 0).all()
+    walk = _walk_connectivity(A, n, np.arange(n), T)
+    nc, _ = connected_components(A, directed=False)
+    gts = np.array(gt, copy=True)
+    gts[::97] = 0
+    cl = ncuts_ref.canonical_labels(lab) + 1
+    sc = metrics_ref.score(cl, cl, gts)
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"), points=points, gt=gt,
+        tarl=np.zeros((0, 0), np.float32) if tarl is None else tarl.astype(np.float32),
+        alpha=alpha, theta=theta, gamma=gamma, T=T, split_lim=0.01, radius=1.0, nnz=A.nnz,
+        labels=lab.astype(np.int32), n_groups=len(groups_ref), group_sizes=np.array([len(g) for g in groups_ref]),
+        n_components=nc, solves=walk["solves"], disconnected_solves=walk["disconnected_solves"],
+        reference_seconds=t_ref, versions=np.array([np.__version__, scipy.__version__]),
+        **{"score_" + k.replace(".", "_"): v for k, v in sc.items()})
+    print(f"{name}: n={n} nnz={A.nnz} comps={nc} groups={len(groups_ref)} solves={walk['solves']} "
+          f"disconnected_solves={walk['disconnected_solves']} reference {t_ref:.0f} s scores={sc}")
+
+
 def blob_pair(seed, n_each=150):
     """Two dense blobs joined by a thin bridge: one connected component, a clear Fiedler cut."""
     rng = np.random.default_rng(seed)
@@ -171,6 +215,13 @@ def scorer_fixture(name, seed, n, RefMetrics, n_gt=12, n_pred=15):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), pred=pred, gt=gt,
                         **{"exp_" + k.replace(".", "_"): v for k, v in exp.items()})
     print(name, exp)
+
+
+def main_cfg1():
+    """`python oracle/gen_golden.py --cfg1`: the two 10k-point fixtures only (minutes, a few GB)."""
+    os.makedirs(OUT, exist_ok=True)
+    make_cfg1_fixture("c1_10k_spatial", 10_000, 0, 25.0, dict(alpha=1.0, theta=0.0, gamma=0.0, T=0.075), False)
+    make_cfg1_fixture("c1_10k_tarl", 10_000, 0, 25.0, dict(alpha=1.0, theta=0.5, gamma=0.0, T=0.03), True)
 
 
 def main():
@@ -220,5 +271,7 @@ def main():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--worker":
         _worker(sys.argv[2], sys.argv[3], int(sys.argv[4]), float(sys.argv[5]))
+    elif len(sys.argv) > 1 and sys.argv[1] == "--cfg1":
+        main_cfg1()
     else:
         main()

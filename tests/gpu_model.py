@@ -7,8 +7,8 @@ eigenvector with its own deterministic solver:
   M = D^-1/2 (w + I) D^-1/2 with the known top eigenvector u1 = D^1/2 1 / sqrt(vol)
   projected out each step; the Ritz pair of the largest eigenvalue of T_m is the pair of
   the 2nd-smallest eigenvalue of L_sym = I - M;
-* disconnected segment -> an explicit null-space vector of L_sym,
-  z = D^1/2 (1_A / vol_A - 1_B / vol_B), (A, B) a bipartition of its connected components;
+* disconnected segment -> split into its connected components in one step (`split_components`: what the
+  reference's recursion does to it, one component per ``eigsh`` call);
 
 then exactly the reference's 10-threshold sweep and recursion.  This file restates
 that algorithm in NumPy, segment by segment, so that (a) the algorithm can be checked
@@ -144,16 +144,56 @@ def sweep(ev, d, w):
     return bmask, best, costs
 
 
-def normalized_cut_model(w, num_points_orig, labels, T=0.01, split_lim=0.01, tol=1e-10, stats=None):
-    """Same recursion and output order as the reference; eigenvector from the model solver."""
+def _eligible(n, num_points_orig, split_lim):
+    return n > 2 and n / (num_points_orig + 1e-8) > split_lim
+
+
+def split_components(ncomp, comp):
+    """What the reference's recursion makes of a DISCONNECTED segment, in one step.
+
+    On a disconnected segment ``eigsh(L, 2, sigma=1e-10)`` returns the indicator vector ``D^1/2 1_C`` of ONE
+    connected component (every component has its own computed "zero" eigenvalue of size ~1e-17 and shift-invert
+    resolves them; which one comes out on top is decided by round-off in SuperLU's factorisation), the sweep cuts
+    exactly that component off at cost 0 (``normalized_cut.py:29-32``) and the recursion goes on with the
+    remainder (``:56-59``): the components are peeled off one at a time, each continuing on its own.  The
+    reference stops peeling when the remainder is no longer eligible (<= 1 % of the chunk, ``:39-40``) and emits
+    that ONE remainder as a group; which components are left in it cannot be reproduced (it is a function of
+    SuperLU's round-off, see ``tools/fullsize_delta.py``), so the device -- and this model -- let every component
+    continue on its own.  Children come in the order of the components' first rows.
+    """
+    n = comp.shape[0]
+    first = np.full(ncomp, n, dtype=np.int64)
+    np.minimum.at(first, comp, np.arange(n))
+    rank = np.empty(ncomp, dtype=np.int64)
+    rank[np.argsort(first)] = np.arange(ncomp)
+    r = rank[comp]
+    return [np.flatnonzero(r == c) for c in range(ncomp)]
+
+
+def normalized_cut_model(w, num_points_orig, labels, T=0.01, split_lim=0.01, tol=1e-10, stats=None, connected_solver=None):
+    """Same recursion as the reference; eigenvector from the model solver on connected segments, the
+    component peel (`split_components`) on disconnected ones.  Groups come out in the device's order: the
+    children of a Fiedler cut mask side first (``normalized_cut.py:57-59``), the children of a disconnected
+    segment in order of their first rows.  ``connected_solver(w) -> ev`` replaces the Lanczos model on connected
+    segments (the tests pass SciPy's shift-invert ``eigsh`` there: "hybrid")."""
     n = w.shape[0]
-    if n > 2 and labels.shape[0] / (num_points_orig + 1e-8) > split_lim:
-        d = np.asarray(w.sum(axis=0)).ravel() + 1.0
+    if _eligible(n, num_points_orig, split_lim):
         ncomp, comp = connected_components(w, directed=False)
         if ncomp > 1:
-            ev = null_vector(w, ncomp, comp)
             if stats is not None:
                 stats["null"] = stats.get("null", 0) + 1
+            if not (0.0 < T):   # the cut costs exactly 0 and the test is mcut < T (:56)
+                return [labels]
+            out = []
+            for idx in split_components(ncomp, comp):
+                out += normalized_cut_model(w[idx][:, idx], num_points_orig, labels[idx], T=T, tol=tol, stats=stats,
+                                            connected_solver=connected_solver)
+            return out
+        d = np.asarray(w.sum(axis=0)).ravel() + 1.0
+        if connected_solver is not None:
+            ev = fix_sign(connected_solver(w))
+            if stats is not None:
+                stats["eigsh"] = stats.get("eigsh", 0) + 1
         else:
             lam, ev, m, resid = lanczos_fiedler(w, labels, tol=tol)
             if stats is not None:
@@ -161,8 +201,10 @@ def normalized_cut_model(w, num_points_orig, labels, T=0.01, split_lim=0.01, tol
                 stats.setdefault("iters", []).append((n, m, lam, resid))
         mask, mcut, _ = sweep(ev, d, w)
         if mcut < T:
-            l1 = normalized_cut_model(w[mask][:, mask], num_points_orig, labels[mask], T=T, tol=tol, stats=stats)
-            l2 = normalized_cut_model(w[~mask][:, ~mask], num_points_orig, labels[~mask], T=T, tol=tol, stats=stats)
+            l1 = normalized_cut_model(w[mask][:, mask], num_points_orig, labels[mask], T=T, tol=tol, stats=stats,
+                                      connected_solver=connected_solver)
+            l2 = normalized_cut_model(w[~mask][:, ~mask], num_points_orig, labels[~mask], T=T, tol=tol, stats=stats,
+                                      connected_solver=connected_solver)
             return l1 + l2
         return [labels]
     return [labels]

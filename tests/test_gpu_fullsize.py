@@ -94,8 +94,9 @@ def test_50k_largest_component_eigen_residual(api):
     assert 0 < lam < 0.1
 
 
-def test_cfg4_trimodal_50k_matches_oracle(api):
-    """BASELINE configs[3] at a size the oracle finishes quickly: TARL + Spatial + DINOv2 (384-d)."""
+def test_cfg4_trimodal_50k_affinity_matches_oracle(api):
+    """BASELINE configs[3]: TARL + Spatial + DINOv2 (384-d) affinity vs the CPU restatement; the partition of
+    this chunk is compared with the unmodified oracle's in tests/test_gpu_goldens.py (full_50000_tri_2)."""
     from autoinst_amd import synth
     ch = synth.synthetic_chunk(50_000, seed=2, tarl=True, dino=True)
     cfg = dict(alpha=1.0, theta=0.5, gamma=0.1)
@@ -104,11 +105,6 @@ def test_cfg4_trimodal_50k_matches_oracle(api):
     assert np.array_equal(A.indptr, B.indptr) and np.array_equal(A.indices, B.indices)
     assert (np.abs(A.data - B.data) / B.data).max() <= 1e-12
     assert abs(A - A.T).max() == 0.0
-    n = A.shape[0]
-    got = ncuts_ref.groups_to_labels(api.ncuts(ch["points"], ch["tarl"], ch["dino"], T=0.005, **cfg), n)
-    ref = ncuts_ref.groups_to_labels(ncuts_ref.normalized_cut(B, n, np.arange(n), T=0.005, fast=True), n)
-    assert api.last_stats()["unconverged"] == 0
-    assert ncuts_ref.adjusted_rand_index(got, ref) >= 0.98
 
 
 def test_cfg3_small_map_chunk_parallel_driver(api):

@@ -139,11 +139,9 @@ def test_end_to_end_from_points(api, name):
     groups = api.ncuts(z["points"], tarl, dino, alpha=float(z["alpha"]), theta=float(z["theta"]), gamma=float(z["gamma"]), T=float(z["T"]))
     lab = ncuts_ref.groups_to_labels(groups, n)
     assert (lab >= 0).all()
-    if int(z["disconnected_solves"]) == 0:
-        assert ncuts_ref.partitions_equal(lab, z["labels"])
-    else:
-        # the reference's own answer on a disconnected segment is an arbitrary null-space vector
-        assert ncuts_ref.adjusted_rand_index(lab, z["labels"]) >= 0.9
+    # equal on every fixture, connected or not: a disconnected segment falls into its connected components, which
+    # is what the reference's recursion makes of it (none of these fixtures has a <= 1 % remainder of several components)
+    assert ncuts_ref.partitions_equal(lab, z["labels"])
 
 
 def test_edge_cases(api):
@@ -166,30 +164,6 @@ def test_edge_cases(api):
     # labels are returned as given
     out = api.normalized_cut(A, 5, np.array([10, 11, 12, 13, 14]), T=0.5)
     assert sorted(x for g in out for x in g.tolist()) == [10, 11, 12, 13, 14]
-
-
-def test_cfg1_10k_spatial_matches_oracle(api):
-    """BASELINE configs[0]: 10k-point chunk, spatial only, T = 0.075 -- partition vs the CPU oracle."""
-    from autoinst_amd import synth
-    pts, gt = synth.surface_chunk(10_000, seed=0)
-    gt = gt.copy()
-    gt[::97] = 0  # the reference scorer needs a background label on both sides (metrics_class.py:323)
-    groups = api.ncuts(pts, alpha=1.0, theta=0.0, gamma=0.0, T=0.075)
-    lab = ncuts_ref.groups_to_labels(groups, pts.shape[0])
-    ref = ncuts_ref.groups_to_labels(ncuts_ref.ncuts(pts, alpha=1.0, theta=0.0, gamma=0.0, T=0.075), pts.shape[0])
-    ari = ncuts_ref.adjusted_rand_index(lab, ref)
-    print("cfg1 ARI", ari, "groups", lab.max() + 1, ref.max() + 1)
-    assert ari >= 0.99, ari
-    # the scorer's greedy matching walks predictions in label order (all confidences are 0.5,
-    # metrics_class.py:193-195), so number the groups canonically on both sides
-    cg, cr = ncuts_ref.canonical_labels(lab) + 1, ncuts_ref.canonical_labels(ref) + 1
-    s_gpu = metrics_ref.score(cg, cg, gt)
-    s_cpu = metrics_ref.score(cr, cr, gt)
-    print("cfg1 scores gpu", s_gpu, "cpu", s_cpu)
-    if ari == 1.0:
-        assert s_gpu == s_cpu
-    for k in ("ap", "S_assoc", "p", "r", "f1"):
-        assert abs(s_gpu[k] - s_cpu[k]) <= 2e-2, (k, s_gpu[k], s_cpu[k])
 
 
 def test_run_to_run_reproducible(api):

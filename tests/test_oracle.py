@@ -118,33 +118,18 @@ def test_partition_helpers():
 
 
 @pytest.mark.parametrize("n", [20_000, 200_000])
-def test_only_the_null_space_separates_oracle_and_device_algorithm(n):
-    """SciPy eigsh on connected segments + the device's null-space rule on disconnected ones gives
-    EXACTLY the partition (and group order) of the device algorithm's model, up to BASELINE.json's full
-    200k-point chunk (80 eigsh calls there; the GPU suite shows device == model on the same graph):
-    every connected solve leads to the same cut; SciPy's arbitrary null-space vector is the only
-    source of oracle-vs-device differences at scale."""
-    from scipy.sparse.csgraph import connected_components
+def test_connected_solves_of_model_and_scipy_lead_to_the_same_cuts(n):
+    """The reference recursion with SciPy's own shift-invert eigsh on every CONNECTED segment (and the component
+    split on disconnected ones, which is what the reference's recursion amounts to there: gpu_model.split_components)
+    gives EXACTLY the partition (and group order) of the device algorithm's model, up to BASELINE.json's full
+    200k-point chunk (the GPU suite shows device == model on the same graph): every connected solve leads to the
+    same cut.  What is left between device and reference is the one <= 1 % remainder per disconnected segment that
+    the reference does not split (tests/golden/full_*.npz, tools/fullsize_delta.py)."""
     from autoinst_amd import synth
     T = 0.03
     ch = synth.synthetic_chunk(n, 0, tarl=True)
     A = ncuts_ref.affinity_sparse(ch["points"], ch["tarl"], alpha=1.0, theta=0.5, gamma=0.0)
-
-    def hybrid(w, labels):
-        if w.shape[0] > 2 and labels.shape[0] / (n + 1e-8) > 0.01:
-            nc, comp = connected_components(w, directed=False)
-            if nc > 1:
-                d = np.asarray(w.sum(axis=0)).ravel() + 1.0
-                ev = gpu_model.null_vector(w, nc, comp)
-            else:
-                _, ev, d = ncuts_ref.fiedler(w)
-                ev = gpu_model.fix_sign(ev)
-            mask, mcut, _ = gpu_model.sweep(ev, d, w)
-            if mcut < T:
-                return hybrid(w[mask][:, mask], labels[mask]) + hybrid(w[~mask][:, ~mask], labels[~mask])
-        return [labels]
-
-    gh = hybrid(A, np.arange(n))
+    gh = gpu_model.normalized_cut_model(A, n, np.arange(n), T=T, connected_solver=lambda w: ncuts_ref.fiedler(w)[1])
     gm = gpu_model.normalized_cut_model(A, n, np.arange(n), T=T)
     assert len(gh) == len(gm) and all(np.array_equal(a, b) for a, b in zip(gh, gm))
 
@@ -178,9 +163,8 @@ def test_sam_factor_sparse_equals_literal_dense():
 
 def test_random_small_clouds_model_equals_reference_with_eigsh():
     """Thirty random clouds: the model of the device algorithm == the reference recursion with SciPy's
-    shift-invert eigsh on every connected segment (and the device's null-space rule on disconnected ones),
+    shift-invert eigsh on every connected segment (and the component split on disconnected ones),
     same groups in the same order."""
-    from scipy.sparse.csgraph import connected_components
     rng = np.random.default_rng(99)
     bad = []
     for case in range(30):
@@ -196,22 +180,7 @@ def test_random_small_clouds_model_equals_reference_with_eigsh():
             pts = rng.uniform(-5, 5, (n, 3))
         T = float(rng.choice([0.02, 0.1, 0.3]))
         A = ncuts_ref.affinity_sparse(pts, None, alpha=1.0, theta=0.0, gamma=0.0)
-
-        def hybrid(w, labels):
-            if w.shape[0] > 2 and labels.shape[0] / (n + 1e-8) > 0.01:
-                nc, comp = connected_components(w, directed=False)
-                if nc > 1:
-                    d = np.asarray(w.sum(axis=0)).ravel() + 1.0
-                    ev = gpu_model.null_vector(w, nc, comp)
-                else:
-                    _, ev, d = ncuts_ref.fiedler(w)
-                    ev = gpu_model.fix_sign(ev)
-                mask, mcut, _ = gpu_model.sweep(ev, d, w)
-                if mcut < T:
-                    return hybrid(w[mask][:, mask], labels[mask]) + hybrid(w[~mask][:, ~mask], labels[~mask])
-            return [labels]
-
-        gh = hybrid(A, np.arange(n))
+        gh = gpu_model.normalized_cut_model(A, n, np.arange(n), T=T, connected_solver=lambda w: ncuts_ref.fiedler(w)[1])
         gm = gpu_model.normalized_cut_model(A, n, np.arange(n), T=T)
         if not (len(gh) == len(gm) and all(np.array_equal(a, b) for a, b in zip(gh, gm))):
             la, lb = ncuts_ref.groups_to_labels(gh, n), ncuts_ref.groups_to_labels(gm, n)
@@ -229,3 +198,46 @@ def test_two_cameras_sparse_equals_literal_dense():
     D = ncuts_ref.affinity_dense(pts, None, dino, sam=sam, **kw)
     A = ncuts_ref.affinity_sparse(pts, None, dino, sam=sam, **kw)
     assert np.array_equal(A.toarray() != 0, D != 0) and np.abs(A.toarray() - D).max() <= 1e-15
+
+
+def _full_pairs():
+    import glob
+    import re
+    out = []
+    for p in sorted(glob.glob(os.path.join(GOLDEN, "full_*_*.npz"))):
+        m = re.fullmatch(r"(full_\d+_[a-z]+_\d+)_([pw]\d+)", os.path.basename(p)[:-4])
+        if m and os.path.exists(os.path.join(GOLDEN, m.group(1) + ".npz")):
+            out.append((m.group(1), m.group(2)))
+    return out
+
+
+@pytest.mark.parametrize("base,tag", _full_pairs())
+def test_the_oracle_disagrees_with_itself_only_under_reordering(base, tag):
+    """The record behind the full-size tolerance (tests/test_gpu_goldens.py).  `_w*` = the same oracle run after
+    other eigsh calls (another ARPACK start-vector state): the partition is the same up to a handful of points.
+    `_p*` = the same points listed in another order: the <= 1 % remainders come out differently (SuperLU's
+    elimination order and round-off decide which component eigsh returns), ARI ~0.997-0.999 -- as far from the
+    oracle as the device is."""
+    import json
+    a = np.load(os.path.join(GOLDEN, base + ".npz"))
+    b = np.load(os.path.join(GOLDEN, f"{base}_{tag}.npz"))
+    la, lb = a["labels"].astype(np.int64), b["labels"].astype(np.int64)
+    ari = ncuts_ref.adjusted_rand_index(la, lb)
+    ma, mb = json.loads(str(a["meta"])), json.loads(str(b["meta"]))
+    print(base, tag, "ARI", ari, "groups", ma["groups"], mb["groups"], {k: mb["scores"][k] - ma["scores"][k] for k in ("ap", "S_assoc", "p")})
+    if tag.startswith("w"):
+        assert ari >= 0.999999 and abs(ma["groups"] - mb["groups"]) <= 1
+    else:
+        assert 0.99 <= ari < 1.0 and abs(ma["groups"] - mb["groups"]) <= 3
+
+
+@pytest.mark.parametrize("name", ["c1_10k_spatial", "c1_10k_tarl"])
+def test_model_equals_the_imported_reference_at_cfg1_size(name):
+    """configs[0]'s own size: the device algorithm's model gives the partition the reference module produced."""
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    tarl = z["tarl"].astype(np.float64) if z["tarl"].size else None
+    n = z["points"].shape[0]
+    A = ncuts_ref.affinity_sparse(z["points"], tarl, alpha=float(z["alpha"]), theta=float(z["theta"]), gamma=float(z["gamma"]))
+    assert A.nnz == int(z["nnz"])
+    g = gpu_model.normalized_cut_model(A, n, np.arange(n), T=float(z["T"]))
+    assert len(g) == int(z["n_groups"]) and ncuts_ref.partitions_equal(ncuts_ref.groups_to_labels(g, n), z["labels"])
