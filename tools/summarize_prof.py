@@ -5,7 +5,7 @@ writes <out>_kernel_stats.csv (rocprofv3's own table) and <out>_summary.txt.
 """
 import csv, glob, shutil, sys
 src, out = sys.argv[1], sys.argv[2]
-f = glob.glob(f"{src}/*/*_kernel_stats.csv")[0]
+f = (glob.glob(f"{src}/*/*_kernel_stats.csv") + glob.glob(f"{src}/*_kernel_stats.csv"))[0]
 shutil.copy(f, out + "_kernel_stats.csv")
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
