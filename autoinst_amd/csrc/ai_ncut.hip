@@ -2619,6 +2619,8 @@ static bool eligible(int n, int64_t n_orig, double split_lim) {
 
 }  // namespace
 
+#include "ai_chfsi.inc"
+
 // ----------------------------------------------------------------------------- C ABI
 static void fill_opts(Solver& S, const ai_ncut_opts* opts) {
   if (!opts) return;
@@ -3147,7 +3149,21 @@ int eigs_connected(ai_ctx* ctx, const ai_csr* csr, const ai_ncut_opts* opts, int
   AI_TRY(out.alloc((size_t)k1 * n));
   std::vector<double> thetas, resids;
   int steps = 0;
-  AI_TRY(S.lanczos_fro(k1, thetas, resids, out.p, (size_t)n, &steps));
+  static const int force_fro = getenv("AI_EIGS_LANCZOS") ? atoi(getenv("AI_EIGS_LANCZOS")) : 0;
+  if (!force_fro && n >= 1024 && k1 >= 3) {
+    // many pairs of a large graph: Chebyshev-filtered subspace iteration (block of 64 / 128 vectors)
+    ChfsiStats cs;
+    if (k1 <= 32)
+      AI_TRY(chfsi_solve<1>(S, k1, S.opt.tol, thetas, resids, out.p, (size_t)n, &cs));
+    else
+      AI_TRY(chfsi_solve<2>(S, k1, S.opt.tol, thetas, resids, out.p, (size_t)n, &cs));
+    steps = cs.spmm;
+    if (getenv("AI_NCUT_DEBUG"))
+      fprintf(stderr, "[ai_eigs chfsi] %d outer iterations, %d polynomial degrees, %d SpMM launches, filter %.1f ms, orthonormalisation + Rayleigh-Ritz %.1f ms\n",
+              cs.outer, cs.degrees, cs.spmm, cs.ms_filter, cs.ms_rr);
+  } else {
+    AI_TRY(S.lanczos_fro(k1, thetas, resids, out.p, (size_t)n, &steps));
+  }
   const int got = (int)thetas.size();
   std::vector<double> h_out((size_t)got * n);
   std::vector<int32_t> h_orig(n);

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[4] for real: a CONNECTED ~1M-row graph through ai_eigs_smallest(k = 64).
+
+The 1M-point synthetic chunk of SURVEY 8d (extent 270 m) has ~1000 components, so its 64 smallest eigenpairs are
+the explicit null space and no Lanczos step runs.  Here the same generator at extent 170 m gives a radius graph whose
+largest component holds 99.8 % of the points (997 816 rows, 48 stored entries per row); that component goes through
+`ai_eigs_smallest`: Chebyshev-filtered subspace iteration on a block of 128 vectors (csrc/ai_chfsi.inc).  Single-vector
+Lanczos with full re-orthogonalisation (`lanczos_fro`, still used for small graphs / few pairs) does NOT converge here
+within its 4000-step cap: 102 s, residual 5e-4 (profiles/r02_cfg5_lanczos_fro.json).  The reference itself only ever asks for k = 2 (normalized_cut.py:49), so parity
+is by properties: residuals, orthonormality, ascending eigenvalues (SciPy comparison at 30k rows: tests/test_gpu_fullsize.py).
+
+    python tools/run_cfg5.py [n] [extent] [k]  -> one JSON line
+"""
+import json, os, sys, time
+import numpy as np
+import scipy.sparse as sp
+from scipy.sparse.csgraph import connected_components
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from autoinst_amd import ncuts_api as api, synth
+from oracle import ncuts_ref   # checker only: residuals are formed with SciPy's CSR product
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+extent = float(sys.argv[2]) if len(sys.argv) > 2 else 170.0
+k = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+tol = 1e-9
+pts, _ = synth.surface_chunk(n, seed=0, extent=extent)
+ctx = api.default_context()
+t0 = time.perf_counter()
+g = api.build_affinity(pts, None, alpha=1.0, theta=0.0, gamma=0.0)
+t_aff = time.perf_counter() - t0
+A = g.to_scipy()
+g.free()
+nc, comp = connected_components(A, directed=False)
+idx = np.flatnonzero(comp == np.bincount(comp).argmax())
+sub = sp.csr_matrix(A[idx][:, idx])
+del A
+N, E = sub.shape[0], sub.nnz
+print(f"largest component {N} of {n} rows ({nc} components), {E} entries", file=sys.stderr, flush=True)
+g = api.DeviceGraph.from_scipy(sub)
+t0 = time.perf_counter()
+evals, V, steps, resid = api.eigs_smallest(g, k, tol=tol, max_iter=4000)
+dt = time.perf_counter() - t0
+ms_spmv, by_spmv = api.bench_spmv(g, 50)
+g.free()
+L, _ = ncuts_ref.laplacian_sym(sub)
+R = L @ V - V * evals[None, :]
+res = np.linalg.norm(R, axis=0)
+orth = np.abs(V.T @ V - np.eye(k)).max()
+m = steps          # SpMM launches of the Chebyshev filter + Rayleigh-Ritz products (block of B vectors each)
+B = 64 if k - 1 <= 32 else 128
+# algorithmic bytes of one fused degree (k_cf_spmm): entries (4 B index + 8 B weight), row pointer + diagonal term, and the
+# block read twice (Y, X_prev) and written once
+spmm_bytes = E * 12.0 + N * 12.0 + 3.0 * N * B * 8.0
+lf = None
+try:
+    lf = json.load(open(os.path.join(ROOT, "profiles", "r02_cfg5_lanczos_fro.json")))
+except (OSError, ValueError):
+    pass
+out = {"config": f"cfg5: largest component of the {n}-point chunk at extent {extent} m, k = {k}, tol {tol}",
+       "solver": f"Chebyshev-filtered subspace iteration, block of {B} vectors (AI_EIGS_LANCZOS=1 selects Lanczos with full re-orthogonalisation)",
+       "rows": N, "entries": E, "components_of_chunk": int(nc), "affinity_ms": 1e3 * t_aff,
+       "eigs_seconds": dt, "spmm_launches": m, "max_residual_reported": resid,
+       "max_true_residual": float(res.max()), "orthonormality": float(orth), "lambda": [float(evals[0]), float(evals[1]), float(evals[-1])],
+       "ascending": bool(np.all(np.diff(evals) >= -1e-12)),
+       "algorithmic_bytes_per_spmm": spmm_bytes, "algorithmic_bytes_filter_total": m * spmm_bytes,
+       "achieved_GBps_whole_solve": m * spmm_bytes / dt / 1e9,
+       "spmv_kernel_us": 1e3 * ms_spmv, "spmv_kernel_GBps": by_spmv / ms_spmv / 1e6, "spmv_frac_of_8TBps": by_spmv / ms_spmv / 1e6 / 8000.0,
+       "lanczos_full_reorth_for_comparison": None if lf is None else {"seconds": lf["eigs_seconds"], "steps": lf["lanczos_steps"],
+                                                                      "max_true_residual": lf["max_true_residual"], "converged": lf["max_true_residual"] <= tol}}
+print(json.dumps(out), flush=True)
