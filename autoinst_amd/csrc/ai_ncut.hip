@@ -510,9 +510,21 @@ __global__ __launch_bounds__(AI_BLOCK) void k_lz_spmv_x(const Task* __restrict__
                                                         const uint16_t* __restrict__ lidx, const int32_t* __restrict__ rowptr,
                                                         const int32_t* __restrict__ col, const double* __restrict__ wm,
                                                         const double* __restrict__ sinv2, const double* __restrict__ Rj,
-                                                        double* __restrict__ Z, double* __restrict__ pA) {
+                                                        double* __restrict__ Z, double* __restrict__ pA,
+                                                        unsigned long long* __restrict__ tstamp) {
   __shared__ double sm[AI_BLOCK / 64];
   __shared__ double xs[AI_ENC_XCAP];
+  // profiling only (opts.reserved bit 1): every block stores when it started and ended on the device clock (plain
+  // stores to its own slot: atomics on one address would serialise the blocks); k_ts_reduce takes min / max
+  struct Stamp {
+    unsigned long long* ts;
+    __device__ explicit Stamp(unsigned long long* p) : ts(p) {
+      if (ts && threadIdx.x == 0) ts[2 * blockIdx.x] = (unsigned long long)wall_clock64();
+    }
+    __device__ ~Stamp() {
+      if (ts && threadIdx.x == 0) ts[2 * blockIdx.x + 1] = (unsigned long long)wall_clock64();
+    }
+  } stamp(tstamp);
   const int t = ai_xcd_task(blockIdx.x, ntask);
   const int act = factive[t];
   const Task tk = ftasks[t];
@@ -583,6 +595,30 @@ __global__ __launch_bounds__(AI_BLOCK) void k_lz_spmv_x(const Task* __restrict__
   }
   const double tot = ai_block_sum(acc, sm);
   if (threadIdx.x == 0) pA[t] = tot;
+}
+
+// span[0] = earliest block start, span[1] = latest block end of one launch (profiling only)
+__global__ __launch_bounds__(AI_BLOCK) void k_ts_reduce(const unsigned long long* __restrict__ ts, int nblk, unsigned long long* __restrict__ span) {
+  __shared__ unsigned long long smn[AI_BLOCK], smx[AI_BLOCK];
+  unsigned long long mn = ~0ull, mx = 0ull;
+  for (int b = threadIdx.x; b < nblk; b += AI_BLOCK) {
+    mn = min(mn, ts[2 * b]);
+    mx = max(mx, ts[2 * b + 1]);
+  }
+  smn[threadIdx.x] = mn;
+  smx[threadIdx.x] = mx;
+  __syncthreads();
+  for (int o = AI_BLOCK / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      smn[threadIdx.x] = min(smn[threadIdx.x], smn[threadIdx.x + o]);
+      smx[threadIdx.x] = max(smx[threadIdx.x], smx[threadIdx.x + o]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    span[0] = smn[0];
+    span[1] = smx[0];
+  }
 }
 
 struct LzSeg {
@@ -1816,6 +1852,9 @@ class Solver {
   hipStream_t st;
   ai_ncut_opts opt{1e-10, 4000, 16, 0};
   bool time_spmv = false;           // opts.reserved bit 0: HIP events around every SpMV launch
+  bool clock_spmv = false;          // opts.reserved bit 1: every SpMV launch stamps its own span on the device clock
+  DevBuf<unsigned long long> tstamps, tblock;  // {start, end} per launch of the current level; per block of the launch in flight
+  double clock_khz = 0.0;
   std::vector<hipEvent_t> evpool;   // 2 per launch of the current level
   DevBuf<unsigned long long> work;  // [rows, nnz] processed by the SpMV kernel
   ai_ncut_stats stats{};
@@ -2189,11 +2228,12 @@ class Solver {
     if (e0) {
       hipExtLaunchKernelGGL((k_lz_spmv_x<16, AI_ROW_ILP>), dim3(lzf.n), dim3(AI_BLOCK), 0, st, e0, e1, 0, (const Task*)lzf.d.p,
                             (const int32_t*)factive.p, lzf.n, (const TaskEnc*)enc.p, (const int32_t*)ucol.p, (const uint16_t*)lidx.p, rowptr, col,
-                            (const double*)wm.p, (const double*)sinv2.p, (const double*)vec(j), Y.p, pA.p);
+                            (const double*)wm.p, (const double*)sinv2.p, (const double*)vec(j), Y.p, pA.p, (unsigned long long*)nullptr);
     } else {
       hipLaunchKernelGGL((k_lz_spmv_x<16, AI_ROW_ILP>), dim3(lzf.n), dim3(AI_BLOCK), 0, st, (const Task*)lzf.d.p, (const int32_t*)factive.p, lzf.n,
                          (const TaskEnc*)enc.p, (const int32_t*)ucol.p, (const uint16_t*)lidx.p, rowptr, col, (const double*)wm.p,
-                         (const double*)sinv2.p, (const double*)vec(j), Y.p, pA.p);
+                         (const double*)sinv2.p, (const double*)vec(j), Y.p, pA.p,
+                         (clock_spmv && tblock.p) ? tblock.p : (unsigned long long*)nullptr);
     }
     AI_KERNEL_CHECK();
     return AI_OK;
@@ -2235,6 +2275,16 @@ class Solver {
     AI_HIP(hipEventRecord(ctx->ev[0], st));
     hipLaunchKernelGGL(k_lz_init, dim3(lzc.n), dim3(AI_BLOCK), 0, st, lzc.d.p, cactive.p, orig, u1.p, vec(0), pB[0].p);
     AI_KERNEL_CHECK();
+    if (clock_spmv) {
+      // slot j: {earliest block start, latest block end} of launch j on the device's wall clock
+      AI_TRY(tstamps.ensure((size_t)2 * (mcap + 1)));
+      AI_TRY(tblock.ensure((size_t)2 * (lzf.n + 1)));
+      if (clock_khz == 0.0) {
+        int khz = 0;
+        AI_HIP(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device));
+        clock_khz = khz > 0 ? (double)khz : 100000.0;
+      }
+    }
     const bool dense_checks = (min_n <= 512);
     int next_check = dense_checks ? 1 : opt.check_every;
     int steps = 0, nchecks = 0, last_check_m = 0;
@@ -2275,6 +2325,10 @@ class Solver {
         AI_TRY(launch_spmv(j, evpool[2 * j], evpool[2 * j + 1]));
       } else {
         AI_TRY(launch_spmv(j));
+        if (clock_spmv && enc_ready && spmv_variant == 0) {
+          hipLaunchKernelGGL(k_ts_reduce, dim3(1), dim3(AI_BLOCK), 0, st, (const unsigned long long*)tblock.p, lzf.n, tstamps.p + 2 * (size_t)j);
+          AI_KERNEL_CHECK();
+        }
       }
       hipLaunchKernelGGL(k_lz_update, dim3(lzc.n), dim3(AI_BLOCK), 0, st, lzc.d.p, cranges.p, L, j, (const double*)pA.p,
                          (const double2*)pB[j & 1].p, pB[(j + 1) & 1].p, u1.p, (const double*)Y.p, (const double*)vec(j),
@@ -2313,6 +2367,13 @@ class Solver {
     if (getenv("AI_NCUT_DEBUG")) {
       fprintf(stderr, "[ai_ncut] level %lld: segments %d (lanczos %d, rows %d..%d), active rows %d, steps %d, checks %d\n",
               (long long)stats.levels, S_, nl, min_n, max_n, na, steps, nchecks);
+    }
+    if (clock_spmv && enc_ready && spmv_variant == 0) {
+      std::vector<unsigned long long> hts((size_t)2 * steps);
+      AI_HIP(hipMemcpyAsync(hts.data(), tstamps.p, hts.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+      AI_HIP(hipStreamSynchronize(st));
+      for (int j = 0; j < steps; ++j)
+        if (hts[2 * j + 1] > hts[2 * j]) stats.ms_spmv += (double)(hts[2 * j + 1] - hts[2 * j]) / clock_khz;
     }
     if (time_spmv) {
       AI_HIP(hipStreamSynchronize(st));
@@ -2628,6 +2689,7 @@ static void fill_opts(Solver& S, const ai_ncut_opts* opts) {
   if (opts->max_iter > 0) S.opt.max_iter = std::min(opts->max_iter, 4000);  // T_m must fit the check kernel's 64 KB of LDS
   if (opts->check_every > 0) S.opt.check_every = opts->check_every;
   S.time_spmv = (opts->reserved & 1) != 0;
+  S.clock_spmv = !S.time_spmv && (opts->reserved & 2) != 0;
 }
 
 // The recursion over one graph that holds `nchunks` independent chunks back to back (rows
@@ -3303,5 +3365,10 @@ extern "C" int ai_eigs_smallest(ai_ctx* ctx, const ai_csr* csr, int32_t k, const
   }
   if (iters) *iters = steps;
   if (max_resid) *max_resid = mr;
+  if (mr > S.opt.tol) {
+    // the reference's eigsh raises ArpackNoConvergence in this situation; the pairs found so far are returned all the same
+    ai_set_error("ai_eigs_smallest: largest residual %.3g after %d steps is above the tolerance %.3g", mr, steps, S.opt.tol);
+    return AI_ERR_NO_CONVERGENCE;
+  }
   return AI_OK;
 }

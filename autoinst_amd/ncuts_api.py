@@ -234,7 +234,9 @@ def get_affinity_matrix(points, tarl=None, dino=None, *, alpha=CONFIG["alpha"], 
 
 
 def _opts(tol, max_iter, check_every, time_spmv=False):
-    return _ffi.NcutOpts(float(tol or 0.0), int(max_iter or 0), int(check_every or 0), 1 if time_spmv else 0)
+    """``time_spmv``: False, True / "events" (HIP events on every SpMV dispatch) or "clock" (device-clock stamps)."""
+    flag = 0 if not time_spmv else (2 if time_spmv == "clock" else 1)
+    return _ffi.NcutOpts(float(tol or 0.0), int(max_iter or 0), int(check_every or 0), flag)
 
 
 def ncuts_labels(graph: DeviceGraph, num_points_orig: int, T: float, split_lim: float = SPLIT_LIM, *,

@@ -112,7 +112,7 @@ typedef struct {
   double tol;           /* Ritz residual |beta_m s_m| at which a Lanczos solve stops (default 1e-10) */
   int32_t max_iter;     /* Lanczos step cap per solve (default 4000) */
   int32_t check_every;  /* steps between convergence checks on large segments (default 16) */
-  int32_t reserved;     /* bit 0: time every SpMV launch with HIP events (fills ms_spmv; for bench.py) */
+  int32_t reserved;     /* profiling, fills ms_spmv (for bench.py): bit 0 = HIP start/stop events on every SpMV dispatch; bit 1 = every SpMV launch stamps its own span (first block in .. last block out) on the device clock, which does not perturb how launches of several streams overlap */
 } ai_ncut_opts;
 
 typedef struct {
@@ -126,7 +126,7 @@ typedef struct {
   int64_t n_groups;
   double ms_total;         /* host wall time of the call */
   double ms_eigen;         /* device time in the Lanczos / Ritz phase (HIP events) */
-  double ms_spmv;          /* device time in the fused SpMV kernel alone (HIP events; only with reserved bit 0) */
+  double ms_spmv;          /* device time in the fused SpMV kernel alone (only with reserved bit 0 or 1) */
   double ms_sweep;         /* device time in min/max + bin + sweep */
   double ms_rebuild;       /* device time in CC + partition + CSR rebuild */
   double max_resid;        /* largest accepted Ritz residual */
