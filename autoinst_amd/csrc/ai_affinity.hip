@@ -165,6 +165,14 @@ __global__ __launch_bounds__(AI_BLOCK) void k_neighbours(const double* __restric
   if (!FILL) cnt[p] = k;
 }
 
+// total of the per-row neighbour counts in 64 bits (the row pointers are int32: a graph with 2^31 or more entries is refused)
+__global__ __launch_bounds__(AI_BLOCK) void k_count_total(const int32_t* __restrict__ cnt, int64_t n, unsigned long long* __restrict__ total) {
+  unsigned long long a = 0;
+  for (int64_t i = (int64_t)blockIdx.x * AI_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * AI_BLOCK) a += (unsigned long long)cnt[i];
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+  if ((threadIdx.x & 63) == 0 && a) atomicAdd(total, a);
+}
+
 // all-zero feature row = "no TARL feature for this point" (ncuts_utils.py:143)
 __global__ __launch_bounds__(AI_BLOCK) void k_zero_rows(const double* __restrict__ f, int32_t dim, const int32_t* __restrict__ orig,
                                                         int64_t n, uint8_t* __restrict__ flag) {
@@ -223,7 +231,7 @@ __global__ __launch_bounds__(AI_BLOCK) void k_weights(const int32_t* __restrict_
   if (row >= n) return;
   const int lane = threadIdx.x & 63;
   const int grp = lane >> 4, t = lane & 15;
-  const int64_t oi = orig[row];
+  const int64_t oi = orig ? orig[row] : row;  // a graph uploaded with ai_csr_from_host has no permutation of its own
   const bool use_t = (theta != 0.0) && tarl != nullptr;
   const bool use_d = (gamma != 0.0) && dino != nullptr;
   const bool nti = use_t ? (notarl[row] != 0) : false;
@@ -249,7 +257,7 @@ __global__ __launch_bounds__(AI_BLOCK) void k_weights(const int32_t* __restrict_
       const int32_t e = eb + 4 * q + grp;
       const bool act = e < e1;
       const int32_t j = act ? col[e] : (int32_t)row;
-      const int64_t oj = orig[j];
+      const int64_t oj = orig ? orig[j] : j;
       double t2 = 0.0, g2 = 0.0;
       if (use_t) {
         const bool skip = nti || (notarl[j] != 0);
@@ -272,7 +280,7 @@ __global__ __launch_bounds__(AI_BLOCK) void k_weights(const int32_t* __restrict_
       if (sam != nullptr && beta != 0.0) {
         // SAM factor (utils/image/image_utils.py:64-89): fraction of the views in which both points carry an
         // id (!= -1) and the ids differ
-        const int64_t oj = orig[col[e]];
+        const int64_t oj = orig ? orig[col[e]] : col[e];
         int co = 0, diff = 0;
         for (int v = 0; v < nviews; ++v) {
           const int32_t a = sam[oi * nviews + v], b = sam[oj * nviews + v];
@@ -624,6 +632,7 @@ extern "C" int ai_affinity_build_sam(ai_ctx* ctx, const double* xyz, int64_t n, 
   A->val = nullptr;
   A->orig = nullptr;
   A->device = ctx->device;
+  ai_register_graph(ctx, A);
   auto fail = [&](int s) {
     ai_csr_free(ctx, A);
     return s;
@@ -669,10 +678,21 @@ extern "C" int ai_affinity_build_sam(ai_ctx* ctx, const double* xyz, int64_t n, 
   hipLaunchKernelGGL(k_neighbours<false>, dim3(gb), dim3(AI_BLOCK), 0, st, X.p, Y.p, Z.p, cellid.p, cstart.p, cend.p, n, g,
                      radius, cnt.p, (const int32_t*)nullptr, (int32_t*)nullptr, (double*)nullptr);
   AI_HIPF(hipGetLastError());
+  DevBuf<unsigned long long> total;
+  AI_TRYF(total.alloc(1));
+  AI_HIPF(hipMemsetAsync(total.p, 0, sizeof(unsigned long long), st));
+  hipLaunchKernelGGL(k_count_total, dim3(256), dim3(AI_BLOCK), 0, st, (const int32_t*)cnt.p, n, total.p);
+  AI_HIPF(hipGetLastError());
   AI_TRYF(ai_exclusive_scan_i32(st, cnt.p, A->rowptr, n, scantmp.p));
   int32_t nnz32 = 0;
+  unsigned long long nnz64 = 0;
   AI_HIPF(hipMemcpyAsync(&nnz32, A->rowptr + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  AI_HIPF(hipMemcpyAsync(&nnz64, total.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   AI_HIPF(hipStreamSynchronize(st));
+  if (nnz64 >= (1ull << 31)) {
+    ai_set_error("ai_affinity_build: the radius graph has %llu entries; this build indexes entries with int32 (< 2^31)", nnz64);
+    return fail(AI_ERR_BAD_ARG);
+  }
   if (nnz32 < n) {
     ai_set_error("ai_affinity_build: internal error, nnz = %d < n (every point is its own neighbour)", nnz32);
     return fail(AI_ERR_INTERNAL);
@@ -742,6 +762,7 @@ extern "C" int ai_affinity_apply_camera(ai_ctx* ctx, ai_csr* csr, const double* 
     return AI_ERR_BAD_ARG;
   }
   if (gamma == 0.0 && beta == 0.0) return AI_OK;
+  AI_CHECK_GRAPH(csr, "ai_affinity_apply_camera");
   AI_HIP(hipSetDevice(ctx->device));
   ArenaScope arena_scope(&ctx->arena);
   hipStream_t st = ctx->stream;

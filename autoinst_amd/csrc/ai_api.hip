@@ -90,7 +90,7 @@ void ai_graph_cache::release(void* p) {
       }
       return;
     }
-  (void)hipFree(p);  // not one of ours (a graph built by another context)
+  // not one of this cache's buffers: leave it alone (ai_csr_free always goes through the owning context)
 }
 
 void ai_graph_cache::release_all() {
@@ -126,49 +126,93 @@ extern "C" int ai_ctx_create(int device, ai_ctx** out) {
   ai_ctx* c = new ai_ctx();
   c->device = device;
   c->num_cu = prop.multiProcessorCount;
-  AI_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  for (int i = 0; i < 8; ++i) AI_HIP(hipEventCreate(&c->ev[i]));
-  AI_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-  for (int i = 0; i < AI_CHECK_DEPTH; ++i) {
-    AI_HIP(hipEventCreateWithFlags(&c->chk_ev[i], hipEventDisableTiming));
-    AI_HIP(hipEventCreateWithFlags(&c->chk_ev1[i], hipEventDisableTiming));
+  c->stream = nullptr;
+  c->side = nullptr;
+  c->pinned = nullptr;
+  c->stage = nullptr;
+  for (int i = 0; i < 8; ++i) c->ev[i] = nullptr;
+  for (int i = 0; i < AI_CHECK_DEPTH; ++i) c->chk_ev[i] = c->chk_ev1[i] = nullptr;
+  // any failure below releases what has been created so far
+  auto build = [&]() -> int {
+    AI_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (int i = 0; i < 8; ++i) AI_HIP(hipEventCreate(&c->ev[i]));
+    AI_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    for (int i = 0; i < AI_CHECK_DEPTH; ++i) {
+      AI_HIP(hipEventCreateWithFlags(&c->chk_ev[i], hipEventDisableTiming));
+      AI_HIP(hipEventCreateWithFlags(&c->chk_ev1[i], hipEventDisableTiming));
+    }
+    AI_HIP(hipHostMalloc((void**)&c->pinned, AI_PINNED_INTS * sizeof(int32_t), hipHostMallocDefault));
+    AI_HIP(hipHostMalloc((void**)&c->stage, AI_STAGE_BYTES, hipHostMallocDefault));
+    return AI_OK;
+  };
+  const int st = build();
+  if (st != AI_OK) {
+    (void)ai_ctx_destroy(c);
+    return st;
   }
-  AI_HIP(hipHostMalloc((void**)&c->pinned, AI_PINNED_INTS * sizeof(int32_t), hipHostMallocDefault));
-  AI_HIP(hipHostMalloc((void**)&c->stage, AI_STAGE_BYTES, hipHostMallocDefault));
   *out = c;
   return AI_OK;
+}
+
+void ai_register_graph(ai_ctx* ctx, ai_csr* g) {
+  g->owner = ctx;
+  std::lock_guard<std::mutex> lock(ctx->graphs_mu);
+  ctx->live_graphs.push_back(g);
 }
 
 extern "C" int ai_ctx_destroy(ai_ctx* ctx) {
   if (!ctx) return AI_OK;
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
-  for (int i = 0; i < 8; ++i) (void)hipEventDestroy(ctx->ev[i]);
-  (void)hipStreamSynchronize(ctx->side);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (int i = 0; i < 8; ++i)
+    if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+  if (ctx->side) (void)hipStreamSynchronize(ctx->side);
   for (int i = 0; i < AI_CHECK_DEPTH; ++i) {
-    (void)hipEventDestroy(ctx->chk_ev[i]);
-    (void)hipEventDestroy(ctx->chk_ev1[i]);
+    if (ctx->chk_ev[i]) (void)hipEventDestroy(ctx->chk_ev[i]);
+    if (ctx->chk_ev1[i]) (void)hipEventDestroy(ctx->chk_ev1[i]);
   }
-  (void)hipStreamDestroy(ctx->side);
+  if (ctx->side) (void)hipStreamDestroy(ctx->side);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->stage) (void)hipHostFree(ctx->stage);
+  {
+    // graphs that outlive their context lose their buffers with it: their handles stay valid to free, and every
+    // other call on them fails with "the graph's context was destroyed" instead of touching freed memory
+    std::lock_guard<std::mutex> lock(ctx->graphs_mu);
+    for (ai_csr* g : ctx->live_graphs) {
+      g->rowptr = nullptr;
+      g->col = nullptr;
+      g->val = nullptr;
+      g->orig = nullptr;
+      g->owner = nullptr;
+    }
+    ctx->live_graphs.clear();
+  }
   ctx->arena.release_all();
-  ctx->graphs.release_all();  // graphs still alive lose their buffers with the context that built them
-  (void)hipStreamDestroy(ctx->stream);
+  ctx->graphs.release_all();
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return AI_OK;
 }
 
+// The buffers go back to the cache of the context that BUILT the graph, whichever context (or none) is passed.
 extern "C" int ai_csr_free(ai_ctx* ctx, ai_csr* csr) {
+  (void)ctx;
   if (!csr) return AI_OK;
-  if (ctx) {
-    (void)hipSetDevice(ctx->device);
-    ctx->graphs.release(csr->rowptr);
-    ctx->graphs.release(csr->col);
-    ctx->graphs.release(csr->val);
-    ctx->graphs.release(csr->orig);
-  }  // without a context only the handle goes: the buffers belong to the context that built the graph
-     // and are released with it at the latest
+  if (ai_ctx* o = csr->owner) {
+    (void)hipSetDevice(o->device);
+    {
+      std::lock_guard<std::mutex> lock(o->graphs_mu);
+      for (size_t i = 0; i < o->live_graphs.size(); ++i)
+        if (o->live_graphs[i] == csr) {
+          o->live_graphs.erase(o->live_graphs.begin() + i);
+          break;
+        }
+    }
+    o->graphs.release(csr->rowptr);
+    o->graphs.release(csr->col);
+    o->graphs.release(csr->val);
+    o->graphs.release(csr->orig);
+  }
   delete csr;
   return AI_OK;
 }
@@ -216,6 +260,7 @@ extern "C" int ai_csr_from_host(ai_ctx* ctx, int64_t n, const int64_t* indptr, c
   A->val = nullptr;
   A->orig = nullptr;
   A->device = ctx->device;
+  ai_register_graph(ctx, A);
   hipError_t e1 = ctx->graphs.alloc((void**)&A->rowptr, (size_t)(n + 1) * sizeof(int32_t));
   hipError_t e2 = ctx->graphs.alloc((void**)&A->col, (size_t)(nnz > 0 ? nnz : 1) * sizeof(int32_t));
   hipError_t e3 = ctx->graphs.alloc((void**)&A->val, (size_t)(nnz > 0 ? nnz : 1) * sizeof(double));
@@ -273,6 +318,10 @@ __global__ __launch_bounds__(AI_BLOCK) void k_export_rows(const int32_t* __restr
 extern "C" int ai_csr_export(ai_ctx* ctx, const ai_csr* csr, int64_t* indptr, int32_t* indices, double* data) {
   if (!ctx || !csr || !indptr || (csr->nnz > 0 && (!indices || !data))) {
     ai_set_error("ai_csr_export: bad argument");
+    return AI_ERR_BAD_ARG;
+  }
+  if (!csr->rowptr) {
+    ai_set_error("ai_csr_export: the graph's context was destroyed");
     return AI_ERR_BAD_ARG;
   }
   AI_HIP(hipSetDevice(ctx->device));

@@ -81,6 +81,7 @@ struct ai_graph_cache {
   void release_all();
 };
 
+struct ai_csr;
 struct ai_ctx {
   int device;
   hipStream_t stream;
@@ -93,7 +94,18 @@ struct ai_ctx {
   ai_arena arena;                      // call-scoped device workspace, kept between calls
   ai_graph_cache graphs;               // buffers of the graphs this context built
   char* stage;                         // AI_STAGE_BYTES of pinned host memory for packed small uploads / downloads
+  std::mutex graphs_mu;                // guards live_graphs (a graph may be freed from another thread)
+  std::vector<ai_csr*> live_graphs;    // graphs this context built and that are still alive: their buffers are the context's
 };
+void ai_register_graph(ai_ctx* ctx, ai_csr* g);   // sets g->owner
+// a graph whose context was destroyed keeps a valid handle (to free) but no buffers
+#define AI_CHECK_GRAPH(g, who)                                          \
+  do {                                                                  \
+    if ((g) && !(g)->rowptr) {                                          \
+      ai_set_error("%s: the graph's context was destroyed", (who));     \
+      return AI_ERR_BAD_ARG;                                            \
+    }                                                                   \
+  } while (0)
 
 struct ai_csr {
   int64_t n;
@@ -103,6 +115,8 @@ struct ai_csr {
   double* val;      // nnz    (device) raw affinities w_ij
   int32_t* orig;    // n      (device) internal row -> caller's original id; nullptr = identity
   int device;
+  ai_ctx* owner = nullptr;  // the context whose buffer cache holds rowptr / col / val / orig; nullptr: buffers are not the handle's
+                            // (a temporary view, or the owner was destroyed: then the pointers above are null as well)
 };
 
 // Device buffer of one API call: carved from the context's arena when one is active (then

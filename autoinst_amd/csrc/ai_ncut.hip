@@ -2963,6 +2963,7 @@ extern "C" int ai_ncut(ai_ctx* ctx, const ai_csr* csr, int64_t num_points_orig, 
     ai_set_error("ai_ncut: bad argument");
     return AI_ERR_BAD_ARG;
   }
+  AI_CHECK_GRAPH(csr, "ai_ncut");
   AI_HIP(hipSetDevice(ctx->device));
   const double t0 = now_ms();
   ArenaScope arena_scope(&ctx->arena);  // declared before the solver: its buffers die first
@@ -2984,6 +2985,7 @@ extern "C" int ai_ncut_batch(ai_ctx* ctx, const ai_csr* const* graphs, int32_t c
       ai_set_error("ai_ncut_batch: null graph / label buffer at position %d", c);
       return AI_ERR_BAD_ARG;
     }
+    AI_CHECK_GRAPH(graphs[c], "ai_ncut_batch");
     N += graphs[c]->n;
     E += graphs[c]->nnz;
   }
@@ -2995,6 +2997,15 @@ extern "C" int ai_ncut_batch(ai_ctx* ctx, const ai_csr* const* graphs, int32_t c
   const double t0 = now_ms();
   ArenaScope arena_scope(&ctx->arena);
   hipStream_t st = ctx->stream;
+  // The frontier's compact order starts with the rows of the chunks that can be split at all (normalized_cut.py:39-40);
+  // chunks that cannot (n <= 2 or below split_lim) are placed behind them, whatever their position in the call.
+  std::vector<int> order;
+  for (int pass = 0; pass < 2; ++pass)
+    for (int c = 0; c < count; ++c)
+      if (eligible((int)graphs[c]->n, num_points_orig[c], split_lim) == (pass == 0)) order.push_back(c);
+  std::vector<int64_t> norig_p(count);
+  std::vector<int32_t*> labels_p(count);
+  std::vector<int32_t> ngroups_p(count, 0);
   // one block-diagonal graph: the chunks back to back (column ids shifted by the chunk's first row)
   DevBuf<int32_t> rp, cl, og;
   DevBuf<double> vl;
@@ -3005,7 +3016,9 @@ extern "C" int ai_ncut_batch(ai_ctx* ctx, const ai_csr* const* graphs, int32_t c
   std::vector<int64_t> off(count + 1, 0);
   int64_t eoff = 0;
   for (int c = 0; c < count; ++c) {
-    const ai_csr* g = graphs[c];
+    const ai_csr* g = graphs[order[c]];
+    norig_p[c] = num_points_orig[order[c]];
+    labels_p[c] = labels_out[order[c]];
     const int64_t n = g->n, e = g->nnz;
     off[c + 1] = off[c] + n;
     hipLaunchKernelGGL(k_offset_copy, dim3((unsigned)((n + 1 + AI_BLOCK - 1) / AI_BLOCK)), dim3(AI_BLOCK), 0, st, rp.p + off[c],
@@ -3030,7 +3043,9 @@ extern "C" int ai_ncut_batch(ai_ctx* ctx, const ai_csr* const* graphs, int32_t c
   merged.val = vl.p;
   merged.orig = og.p;
   merged.device = ctx->device;
-  return ncut_impl(ctx, &merged, count, off.data(), num_points_orig, T, split_lim, opts, labels_out, n_groups, stats_out, t0);
+  const int rc = ncut_impl(ctx, &merged, count, off.data(), norig_p.data(), T, split_lim, opts, labels_p.data(), ngroups_p.data(), stats_out, t0);
+  for (int c = 0; c < count; ++c) n_groups[order[c]] = ngroups_p[c];
+  return rc;
 }
 
 extern "C" int ai_fiedler(ai_ctx* ctx, const ai_csr* csr, const ai_ncut_opts* opts, double* lambda2, double* ev_out, int32_t* iters,
@@ -3039,6 +3054,7 @@ extern "C" int ai_fiedler(ai_ctx* ctx, const ai_csr* csr, const ai_ncut_opts* op
     ai_set_error("ai_fiedler: bad argument");
     return AI_ERR_BAD_ARG;
   }
+  AI_CHECK_GRAPH(csr, "ai_fiedler");
   AI_HIP(hipSetDevice(ctx->device));
   ArenaScope arena_scope(&ctx->arena);  // declared before the solver: its buffers die first
   Solver S(ctx, csr);
@@ -3077,6 +3093,7 @@ extern "C" int ai_sweep(ai_ctx* ctx, const ai_csr* csr, const double* ev, double
     ai_set_error("ai_sweep: bad argument");
     return AI_ERR_BAD_ARG;
   }
+  AI_CHECK_GRAPH(csr, "ai_sweep");
   AI_HIP(hipSetDevice(ctx->device));
   ArenaScope arena_scope(&ctx->arena);  // declared before the solver: its buffers die first
   Solver S(ctx, csr);
@@ -3118,6 +3135,7 @@ extern "C" int ai_lsym_apply(ai_ctx* ctx, const ai_csr* csr, const double* x, do
     ai_set_error("ai_lsym_apply: bad argument");
     return AI_ERR_BAD_ARG;
   }
+  AI_CHECK_GRAPH(csr, "ai_lsym_apply");
   AI_HIP(hipSetDevice(ctx->device));
   ArenaScope arena_scope(&ctx->arena);  // declared before the solver: its buffers die first
   Solver S(ctx, csr);
@@ -3149,6 +3167,7 @@ extern "C" int ai_bench_spmv(ai_ctx* ctx, const ai_csr* csr, int32_t reps, doubl
     ai_set_error("ai_bench_spmv: bad argument");
     return AI_ERR_BAD_ARG;
   }
+  AI_CHECK_GRAPH(csr, "ai_bench_spmv");
   AI_HIP(hipSetDevice(ctx->device));
   ArenaScope arena_scope(&ctx->arena);  // declared before the solver: its buffers die first
   Solver S(ctx, csr);
@@ -3254,6 +3273,7 @@ extern "C" int ai_eigs_smallest(ai_ctx* ctx, const ai_csr* csr, int32_t k, const
     ai_set_error("ai_eigs_smallest: bad argument (1 <= k <= %d, k <= n)", RITZ_MAXK);
     return AI_ERR_BAD_ARG;
   }
+  AI_CHECK_GRAPH(csr, "ai_eigs_smallest");
   AI_HIP(hipSetDevice(ctx->device));
   ArenaScope arena_scope(&ctx->arena);
   Solver S(ctx, csr);

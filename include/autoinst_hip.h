@@ -102,15 +102,17 @@ int ai_csr_dims(const ai_csr* csr, int64_t* n, int64_t* nnz);
 int ai_csr_export(ai_ctx* ctx, const ai_csr* csr, int64_t* indptr, int32_t* indices, double* data);
 
 /*
- * Release a graph.  `ctx` must be the context that built it: the device buffers go back to that
- * context's cache (hipFree would synchronise the whole device and stall other host threads) and are
- * re-used by its next graph of similar size; everything is returned to the driver by ai_ctx_destroy.
+ * Release a graph.  The device buffers go back to the cache of the context that BUILT the graph, whichever
+ * context (or NULL) is passed here (hipFree would synchronise the whole device and stall other host threads);
+ * they are re-used by that context's next graph of similar size and returned to the driver by ai_ctx_destroy.
+ * A graph that outlives its context keeps a valid handle (free it as usual) but no buffers: every other call
+ * on it returns AI_ERR_BAD_ARG ("the graph's context was destroyed").
  */
 int ai_csr_free(ai_ctx* ctx, ai_csr* csr);
 
 typedef struct {
   double tol;           /* Ritz residual |beta_m s_m| at which a Lanczos solve stops (default 1e-10) */
-  int32_t max_iter;     /* Lanczos step cap per solve (default 4000) */
+  int32_t max_iter;     /* Lanczos step cap per solve (default 4000; larger values are clamped to 4000: the convergence check keeps T_m in 64 KB of LDS) */
   int32_t check_every;  /* steps between convergence checks on large segments (default 16) */
   int32_t reserved;     /* profiling, fills ms_spmv (for bench.py): bit 0 = HIP start/stop events on every SpMV dispatch; bit 1 = every SpMV launch stamps its own span (first block in .. last block out) on the device clock, which does not perturb how launches of several streams overlap */
 } ai_ncut_opts;
@@ -118,7 +120,7 @@ typedef struct {
 typedef struct {
   int64_t levels;          /* frontier levels processed */
   int64_t lanczos_solves;  /* connected segments solved by Lanczos */
-  int64_t null_solves;     /* disconnected segments given a null-space vector */
+  int64_t null_solves;     /* disconnected segments, split into their connected components in one step */
   int64_t lanczos_steps;   /* sum over levels of lock-step Lanczos steps (= fused SpMV launches) */
   int64_t spmv_rows;       /* rows processed by the SpMV kernel, summed over launches (exact, counted on device) */
   int64_t spmv_nnz;        /* stored entries processed by the SpMV kernel, summed over launches */

@@ -583,3 +583,60 @@ def test_no_convergence_is_an_error_like_the_reference(api):
     lab, ng, st = api.ncuts_labels(g, g.n, 0.075)          # the context is still usable afterwards
     assert st["unconverged"] == 0 and ng >= 1
     g.free()
+
+
+def test_batch_accepts_an_unsplittable_chunk_anywhere(api):
+    """A chunk too small to be split (n <= 2, or below split_lim of its own original size) may sit at any position
+    of a batched call: the library orders the frontier itself (normalized_cut.py:39-40 gate per chunk)."""
+    from autoinst_amd import synth
+    big = [synth.synthetic_chunk(n, seed, tarl=True) for n, seed in ((6000, 1), (5000, 2))]
+    tiny = np.array([[0.0, 0.0, 0.0], [0.2, 0.0, 0.0]])
+    g_big = [api.build_affinity(c["points"], c["tarl"], alpha=1.0, theta=0.5, gamma=0.0) for c in big]
+    g_tiny = api.build_affinity(tiny, None, alpha=1.0, theta=0.0, gamma=0.0)
+    single = [api.ncuts_labels(g, g.n, 0.03) for g in g_big]
+    graphs = [g_big[0], g_tiny, g_big[1]]
+    labs, ngs, st = api.ncuts_labels_batch(graphs, [g_big[0].n, 2, 10 ** 9], 0.03)
+    assert ngs[1] == 1 and np.all(labs[1] == 0)
+    assert ngs[0] == single[0][1] and np.array_equal(labs[0], single[0][0])
+    assert ngs[2] == 1 and np.all(labs[2] == 0)          # below split_lim of its (huge) original size
+    labs, ngs, _ = api.ncuts_labels_batch(graphs, None, 0.03)
+    assert np.array_equal(labs[2], single[1][0]) and ngs[2] == single[1][1] and ngs[1] == 1
+
+
+def test_graph_ownership_across_contexts(api):
+    """A graph's buffers belong to the context that built it: freeing it through another context is safe, and a
+    graph that outlives its context fails cleanly instead of touching freed memory."""
+    from autoinst_amd import _ffi, synth
+    import ctypes as C
+    lib = _ffi.load()
+    ch = synth.synthetic_chunk(3000, seed=4, tarl=False, extent=14.0)
+    a, b = api.Context(0), api.Context(0)
+    g = api.build_affinity(ch["points"], None, alpha=1.0, theta=0.0, gamma=0.0, ctx=a)
+    ref = g.to_scipy()
+    assert lib.ai_csr_free(b._h, g._h) == 0     # foreign context: goes back to a's cache all the same
+    g._h = None
+    g2 = api.build_affinity(ch["points"], None, alpha=1.0, theta=0.0, gamma=0.0, ctx=a)   # re-uses the cached buffers
+    assert abs(g2.to_scipy() - ref).max() == 0.0
+    a.close()                                   # g2 outlives its context
+    lab = np.empty(g2.n, dtype=np.int32)
+    ng = C.c_int32()
+    rc = lib.ai_ncut(b._h, g2._h, g2.n, 0.03, 0.01, None, lab.ctypes.data, C.byref(ng), None)
+    assert rc == -1 and b"context was destroyed" in lib.ai_last_error()   # AI_ERR_BAD_ARG
+    g2.free()
+    b.close()
+
+
+def test_apply_camera_on_an_uploaded_graph(api):
+    """ai_affinity_apply_camera on a graph that came from ai_csr_from_host (no permutation of its own)."""
+    from autoinst_amd import _ffi
+    import ctypes as C
+    rng = np.random.default_rng(8)
+    pts = rng.normal(0, 1.0, (300, 3))
+    dino = rng.normal(0, 1, (300, 384))
+    A = ncuts_ref.affinity_sparse(pts, None, alpha=1.0)
+    want = ncuts_ref.affinity_sparse(pts, None, [dino], alpha=1.0, gamma=0.07)
+    g = api.DeviceGraph.from_scipy(A)
+    d = np.ascontiguousarray(dino)
+    _ffi.check(_ffi.load().ai_affinity_apply_camera(g.ctx._h, g._h, d.ctypes.data, 384, None, 0, 0.0, 0.07, _ffi.AI_MEM_HOST), "apply_camera")
+    got = g.to_scipy()
+    assert np.array_equal(got.indices, want.indices) and (np.abs(got.data - want.data) / want.data).max() <= 1e-12
