@@ -1,0 +1,9 @@
+// Tile shapes and capacities shared by the kernels and the host driver of the recursion (ai_ncut.hip, ai_eigs.hip).
+#pragma once
+#define AI_FINE_ROWS 32      // rows per block in the 16-lanes-per-row kernels (2 rows in flight per lane group; 16 / 128 measured slower, 64 equal in throughput and 7 % slower for one chunk)
+#define AI_COARSE_ROWS 512   // rows per block in the thread-per-row kernels (256 / 1024 measured within 2 %)
+#define AI_ROW_ILP (AI_FINE_ROWS / (AI_BLOCK / AI_LPR))
+#define AI_SLAB_VECS 32      // Lanczos vectors per HBM slab
+#define AI_ROW_PF 4         // rounds of 16 entries per row loaded together in the 16-lanes-per-row kernels
+#define AI_SWEEP_VALS 40     // per-task sweep partials: cut[10], assocA[10], assocB[10], cntA[10]
+#define AI_MAX_CHECKS 4096   // convergence checks per level (one counter slot each)
