@@ -30,7 +30,10 @@ __all__ = ["Context", "DeviceGraph", "get_affinity_matrix", "build_affinity", "n
 
 
 class Context:
-    """One HIP stream on one GPU (``ai_ctx``).  Not thread-safe; one per process per GPU."""
+    """One main + one check HIP stream, workspace arena and graph-buffer cache on one GPU (``ai_ctx``).
+
+    Not thread-safe: one per host thread (several per process are fine and are how one GPU is kept busy, see bench.py);
+    ``device`` defaults to ``LOCAL_RANK``."""
 
     def __init__(self, device: int | None = None):
         lib = _ffi.load()
