@@ -173,16 +173,29 @@ int ai_exclusive_scan_i32(hipStream_t stream, const int32_t* in, int32_t* out, i
 #define AI_BLOCK 256
 #define AI_LPR 16   // lanes per row in the row-parallel kernels (neighbour counts are ~30-40)
 
-__device__ __forceinline__ double ai_wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Lane exchanges inside a 16-lane DPP row run on the VALU (v_mov_b32 with a dpp modifier); __shfl_xor compiles to
+// ds_bpermute_b32, i.e. goes through the LDS pipe: in the Lanczos SpMV 56 of 71 LDS instructions were such shuffles and
+// kept the LDS pipe busy for 30 % of the kernel (SQ_LDS_IDX_ACTIVE, profiles/r02_pmc_lds_pipe.txt).
+template <int CTRL>
+__device__ __forceinline__ double ai_dpp(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// sum over the 16 lanes of a row; every lane gets the total.  Tree: pairs, quads (quad_perm), halves (row_half_mirror),
+// row (row_mirror) -- a fixed order, so results stay reproducible run to run.
+__device__ __forceinline__ double ai_group16_sum(double v) {
+  v += ai_dpp<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += ai_dpp<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += ai_dpp<0x141>(v);  // row_half_mirror
+  v += ai_dpp<0x140>(v);  // row_mirror
   return v;
 }
-__device__ __forceinline__ double ai_group16_sum(double v) {
-  v += __shfl_xor(v, 8, 16);
-  v += __shfl_xor(v, 4, 16);
-  v += __shfl_xor(v, 2, 16);
-  v += __shfl_xor(v, 1, 16);
+__device__ __forceinline__ double ai_wave_sum(double v) {
+  v = ai_group16_sum(v);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
   return v;
 }
 // Every thread of the block returns the same value; fixed summation order -> reproducible.
