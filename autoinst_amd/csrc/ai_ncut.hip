@@ -535,7 +535,7 @@ extern "C" int ai_bench_spmv(ai_ctx* ctx, const ai_csr* csr, int32_t reps, doubl
     // the four-vector kernel of the block Lanczos path on the same whole-graph frontier
     hipLaunchKernelGGL((k_bl_spmm<16, AI_ROW_ILP>), dim3(S.lzf.n), dim3(AI_BLOCK), 0, st, (const Task*)S.lzf.d.p, (const int32_t*)S.factive.p, S.lzf.n,
                        (const TaskEnc*)S.enc.p, (const int32_t*)S.ucol.p, (const uint16_t*)S.lidx.p, S.rowptr, S.col, (const double*)S.wm.p,
-                       (const double*)S.sinv2.p, (const double*)S.vecb(0), S.Y4.p, S.bl_pH.p, (unsigned long long*)nullptr, S.bl_dbg);
+                       (const double*)S.sinv2.p, (const double*)S.vecb(0), S.Y4.p, S.bl_pH.p, (unsigned long long*)nullptr);
     AI_KERNEL_CHECK();
     return AI_OK;
   };

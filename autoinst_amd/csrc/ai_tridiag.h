@@ -12,6 +12,3 @@ double ai_tridiag_eigval(const double* a, const double* b, int m, int idx, doubl
 void ai_tridiag_eigvec(const double* a, const double* b, int m, double theta, const std::vector<std::vector<double>>& prev,
                        const std::vector<int>& cluster, std::vector<double>& x);
 
-// Symmetric band matrix of half-bandwidth 4 (block Lanczos, block size 4): diagonals bd[k * ld + i] = T(i, i - k), k = 0..4.
-// Largest eigenvalue (theta_out) and its unit eigenvector s (n entries); `hint` as for ai_tridiag_top.
-void ai_band4_top(const double* bd, size_t ld, int n, const double* hint, double* theta_out, std::vector<double>& s);

@@ -184,92 +184,3 @@ void ai_tridiag_eigvec(const double* a, const double* b, int m, double theta, co
   const double rn = 1.0 / sqrt(n2);
   for (int i = 0; i < m; ++i) x[i] *= rn;
 }
-
-
-// ----------------------------------------------------------------------------- band matrix of half-bandwidth 4
-// eigenvalues below x = negative pivots of the L D L^T factorisation of T - x I (no pivoting; a vanishing pivot is nudged)
-static int band4_sturm_lt(const double* bd, size_t ld, int n, double x, std::vector<double>* Lout, std::vector<double>* dout) {
-  // L(i, i - 1 - k) kept row-wise: Lr[4 i + k]
-  std::vector<double> Lr((size_t)4 * n, 0.0), dv(n, 0.0);
-  int cnt = 0;
-  for (int i = 0; i < n; ++i) {
-    for (int k = 3; k >= 0; --k) {  // columns i - 4 .. i - 1 in increasing order
-      const int c = i - 1 - k;
-      if (c < 0) continue;
-      double t = bd[(size_t)(k + 1) * ld + i];
-      for (int q = k + 1; q < 4; ++q) {
-        const int cc = i - 1 - q;
-        if (cc >= 0) t -= Lr[(size_t)4 * i + q] * Lr[(size_t)4 * c + (q - k - 1)] * dv[cc];
-      }
-      Lr[(size_t)4 * i + k] = t / dv[c];
-    }
-    double dd = bd[i] - x;
-    for (int k = 0; k < 4; ++k)
-      if (i - 1 - k >= 0) dd -= Lr[(size_t)4 * i + k] * Lr[(size_t)4 * i + k] * dv[i - 1 - k];
-    if (dd == 0.0) dd = -1e-300;
-    dv[i] = dd;
-    if (dd < 0.0) ++cnt;
-  }
-  if (Lout) Lout->swap(Lr);
-  if (dout) dout->swap(dv);
-  return cnt;
-}
-
-void ai_band4_top(const double* bd, size_t ld, int n, const double* hint, double* theta_out, std::vector<double>& s) {
-  s.assign(n, 0.0);
-  if (n == 1) {
-    *theta_out = bd[0];
-    s[0] = 1.0;
-    return;
-  }
-  double lo = -1e300, hi = -1e300;
-  for (int i = 0; i < n; ++i) {
-    double rad = 0.0;
-    for (int k = 1; k <= 4; ++k) {
-      if (i - k >= 0) rad += fabs(bd[(size_t)k * ld + i]);
-      if (i + k < n) rad += fabs(bd[(size_t)k * ld + i + k]);
-    }
-    lo = std::max(lo, bd[i]);
-    hi = std::max(hi, bd[i] + rad);
-  }
-  lo -= 1e-14 * std::max(fabs(lo), 1.0);
-  hi += 1e-14 * std::max(fabs(hi), 1.0);
-  if (hint) {
-    const double w = 1e-13 * std::max(fabs(*hint), 1.0);
-    const double l2 = *hint - w, h2 = *hint + w;
-    if (l2 > lo && band4_sturm_lt(bd, ld, n, l2, nullptr, nullptr) < n) lo = l2;
-    if (h2 < hi && band4_sturm_lt(bd, ld, n, h2, nullptr, nullptr) == n) hi = h2;
-  }
-  for (int it = 0; it < 200; ++it) {
-    const double mid = 0.5 * (lo + hi);
-    if (mid <= lo || mid >= hi) break;
-    if (band4_sturm_lt(bd, ld, n, mid, nullptr, nullptr) == n) hi = mid; else lo = mid;
-  }
-  *theta_out = 0.5 * (lo + hi);
-  // inverse iteration with a shift just ABOVE the eigenvalue: T - sigma I is negative definite, L D L^T is stable unpivoted
-  const double sigma = hi + 4.0 * (hi - lo) + 1e-15 * std::max(fabs(hi), 1.0);
-  std::vector<double> Lr, dv;
-  band4_sturm_lt(bd, ld, n, sigma, &Lr, &dv);
-  std::vector<double> x(n);
-  for (int i = 0; i < n; ++i) x[i] = 1.0 + 0.001 * ((i * 2654435761u) % 1000) / 1000.0;
-  for (int iter = 0; iter < 3; ++iter) {
-    for (int i = 0; i < n; ++i) {
-      double t = x[i];
-      for (int k = 0; k < 4; ++k)
-        if (i - 1 - k >= 0) t -= Lr[(size_t)4 * i + k] * x[i - 1 - k];
-      x[i] = t;
-    }
-    for (int i = 0; i < n; ++i) x[i] /= dv[i];
-    for (int i = n - 1; i >= 0; --i) {
-      double t = x[i];
-      for (int k = 0; k < 4; ++k)
-        if (i + 1 + k < n) t -= Lr[(size_t)4 * (i + 1 + k) + k] * x[i + 1 + k];
-      x[i] = t;
-    }
-    double n2 = 0.0;
-    for (int i = 0; i < n; ++i) n2 += x[i] * x[i];
-    const double rn = 1.0 / sqrt(n2);
-    for (int i = 0; i < n; ++i) x[i] *= rn;
-  }
-  s = x;
-}
