@@ -119,8 +119,12 @@ __device__ __forceinline__ double dist3(double ax, double ay, double az, double 
   return __dsqrt_rn(s);
 }
 
-// One thread per (sorted) point: walk the 27 neighbouring cells.  FILL = false counts the
-// neighbours within the radius; FILL = true writes their ids and distances.
+// AI_NB_LANES lanes per (sorted) point walk the 27 neighbouring cells: the candidates of a cell are taken AI_NB_LANES at a
+// time (consecutive sorted points: one coalesced read of X / Y / Z each), the neighbours of a round are compacted in
+// candidate order with a ballot, so a row's entries keep the order cell by cell, point by point.  FILL = false counts
+// the neighbours within the radius; FILL = true writes their ids and distances.  (One thread per point walking the ~115
+// candidates serially took 0.16 + 0.24 ms per 200k-point chunk.)
+#define AI_NB_LANES 8
 template <bool FILL>
 __global__ __launch_bounds__(AI_BLOCK) void k_neighbours(const double* __restrict__ X, const double* __restrict__ Y,
                                                          const double* __restrict__ Z, const int32_t* __restrict__ cellid,
@@ -128,41 +132,55 @@ __global__ __launch_bounds__(AI_BLOCK) void k_neighbours(const double* __restric
                                                          int64_t n, Grid g, double radius, int32_t* __restrict__ cnt,
                                                          const int32_t* __restrict__ rowptr, int32_t* __restrict__ col,
                                                          double* __restrict__ dist) {
-  const int64_t p = (int64_t)blockIdx.x * AI_BLOCK + threadIdx.x;
-  if (p >= n) return;
-  const double x = X[p], y = Y[p], z = Z[p];
-  const int32_t c = cellid[p];
+  const int64_t gid = (int64_t)blockIdx.x * AI_BLOCK + threadIdx.x;
+  const int64_t p = gid / AI_NB_LANES;
+  const int l = (int)(gid % AI_NB_LANES);
+  const int sub = (threadIdx.x & 63) / AI_NB_LANES;  // which group of the wave
+  const bool live = p < n;
+  // every lane of the wave runs the same loops (ballots need the whole wave); a dead group simply finds nothing
+  const int64_t pp = live ? p : n - 1;
+  const double x = X[pp], y = Y[pp], z = Z[pp];
+  const int32_t c = cellid[pp];
   const int cx = c % g.nx, cy = (c / g.nx) % g.ny, cz = c / (g.nx * g.ny);
   int32_t k = 0;
-  int32_t base = 0;
-  if (FILL) base = rowptr[p];
+  const int32_t base = (FILL && live) ? rowptr[p] : 0;
   for (int dz = -1; dz <= 1; ++dz) {
     const int zz = cz + dz;
-    if (zz < 0 || zz >= g.nz) continue;
     for (int dy = -1; dy <= 1; ++dy) {
       const int yy = cy + dy;
-      if (yy < 0 || yy >= g.ny) continue;
       for (int dx = -1; dx <= 1; ++dx) {
         const int xx = cx + dx;
-        if (xx < 0 || xx >= g.nx) continue;
-        const int32_t cc = (zz * g.ny + yy) * g.nx + xx;
-        const int32_t s = cstart[cc];
-        if (s < 0) continue;
-        const int32_t e = cend[cc];
-        for (int32_t q = s; q < e; ++q) {
-          const double d = dist3(x, y, z, X[q], Y[q], Z[q]);
-          if (d <= radius) {
-            if (FILL) {
-              col[base + k] = q;
-              dist[base + k] = d;
-            }
-            ++k;
+        const bool in = live && zz >= 0 && zz < g.nz && yy >= 0 && yy < g.ny && xx >= 0 && xx < g.nx;
+        const int32_t cc = in ? (zz * g.ny + yy) * g.nx + xx : 0;
+        int32_t s = in ? cstart[cc] : 0;
+        const int32_t e = (in && s >= 0) ? cend[cc] : 0;
+        if (s < 0) s = 0;
+        // rounds of AI_NB_LANES candidates; groups of one wave may need different numbers of rounds
+        int rounds = (e - s + AI_NB_LANES - 1) / AI_NB_LANES;
+        int wr = rounds;
+#pragma unroll
+        for (int o = 32; o >= AI_NB_LANES; o >>= 1) wr = max(wr, __shfl_xor(wr, o, 64));
+        for (int it = 0; it < wr; ++it) {
+          const int32_t q = s + it * AI_NB_LANES + l;
+          bool hit = false;
+          double d = 0.0;
+          if (it < rounds && q < e) {
+            d = dist3(x, y, z, X[q], Y[q], Z[q]);
+            hit = d <= radius;
           }
+          const unsigned long long bal = __ballot(hit);
+          const unsigned int gbits = (unsigned int)((bal >> (sub * AI_NB_LANES)) & ((1u << AI_NB_LANES) - 1u));
+          if (FILL && hit) {
+            const int before = __popc(gbits & ((1u << l) - 1u));
+            col[base + k + before] = q;
+            dist[base + k + before] = d;
+          }
+          k += __popc(gbits);
         }
       }
     }
   }
-  if (!FILL) cnt[p] = k;
+  if (!FILL && live && l == 0) cnt[p] = k;
 }
 
 // total of the per-row neighbour counts in 64 bits (the row pointers are int32: a graph with 2^31 or more entries is refused)
@@ -675,7 +693,8 @@ extern "C" int ai_affinity_build_sam(ai_ctx* ctx, const double* xyz, int64_t n, 
   AI_HIPF(hipMemsetAsync(cend.p, 0, (size_t)ncell * sizeof(int32_t), st));
   hipLaunchKernelGGL(k_cell_ranges, dim3(gb), dim3(AI_BLOCK), 0, st, cellid.p, n, cstart.p, cend.p);
   AI_HIPF(hipGetLastError());
-  hipLaunchKernelGGL(k_neighbours<false>, dim3(gb), dim3(AI_BLOCK), 0, st, X.p, Y.p, Z.p, cellid.p, cstart.p, cend.p, n, g,
+  const unsigned gnb = (unsigned)((n * AI_NB_LANES + AI_BLOCK - 1) / AI_BLOCK);
+  hipLaunchKernelGGL(k_neighbours<false>, dim3(gnb), dim3(AI_BLOCK), 0, st, X.p, Y.p, Z.p, cellid.p, cstart.p, cend.p, n, g,
                      radius, cnt.p, (const int32_t*)nullptr, (int32_t*)nullptr, (double*)nullptr);
   AI_HIPF(hipGetLastError());
   DevBuf<unsigned long long> total;
@@ -700,7 +719,7 @@ extern "C" int ai_affinity_build_sam(ai_ctx* ctx, const double* xyz, int64_t n, 
   A->nnz = nnz32;
   AI_HIPF(ctx->graphs.alloc((void**)&A->col, (size_t)A->nnz * sizeof(int32_t)));
   AI_HIPF(ctx->graphs.alloc((void**)&A->val, (size_t)A->nnz * sizeof(double)));
-  hipLaunchKernelGGL(k_neighbours<true>, dim3(gb), dim3(AI_BLOCK), 0, st, X.p, Y.p, Z.p, cellid.p, cstart.p, cend.p, n, g,
+  hipLaunchKernelGGL(k_neighbours<true>, dim3(gnb), dim3(AI_BLOCK), 0, st, X.p, Y.p, Z.p, cellid.p, cstart.p, cend.p, n, g,
                      radius, (int32_t*)nullptr, (const int32_t*)A->rowptr, A->col, A->val);
   AI_HIPF(hipGetLastError());
   if (d_tarl) {
