@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""BASELINE.json configs[0], [3], [4] on one GPU (configs[1] is bench.py, configs[2] tools/run_cfg3.py).
+"""BASELINE.json configs[0], [3] on one GPU (configs[1] is bench.py, configs[2] tools/run_cfg3.py, configs[4] tools/run_cfg5.py).
 
     python tools/run_cfgs.py            # prints one JSON line per config
 """
@@ -48,16 +48,7 @@ def main():
     _, dt = timed(cfg4_dev)
     print(json.dumps({"config": "cfg4 affinity only, features resident in HBM", "ms": 1e3 * dt}), flush=True)
     del tp, tt, td, ch
-    # cfg5: 1M points, spatial only, 64 smallest eigenpairs + the SpMV kernel alone
-    ch = synth.synthetic_chunk(1_000_000, 0, tarl=False)
-    g = api.build_affinity(ch["points"], None, alpha=1.0, theta=0.0, gamma=0.0)
-    t0 = time.perf_counter()
-    ev, vecs, steps, resid = api.eigs_smallest(g, 64)
-    dt = time.perf_counter() - t0
-    ms, by = api.bench_spmv(g, 50)
-    print(json.dumps({"config": "cfg5 1M spatial k=64", "n": g.n, "nnz": g.nnz, "eigs_s": dt, "max_eval": float(np.max(ev)),
-                      "spmv_us": 1e3 * ms, "spmv_GBps": by / ms / 1e6}), flush=True)
-    g.free()
+    # cfg5 (1M points, k = 64) has its own driver: tools/run_cfg5.py
 
 
 if __name__ == "__main__":
