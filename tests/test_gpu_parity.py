@@ -662,3 +662,30 @@ def test_block_lanczos_path_gives_the_same_partitions(api, monkeypatch):
     assert n0 == n1 and np.array_equal(l0, l1)
     assert lam == pytest.approx(float(z["eigvals"][1]), rel=1e-8) and resid <= 1e-10
     assert np.abs(np.abs(ev) - z["fiedler_abs"]).max() <= 1e-7
+
+
+def test_thousands_of_isolated_points_and_small_components(api):
+    """A disconnected segment is split into ALL its components at once: 2 000 isolated points, 300 pairs and one blob of
+    1 500 points come out as 2 000 + 300 + (the blob's own groups) groups; the model agrees group for group."""
+    rng = np.random.default_rng(3)
+    gx, gy = np.meshgrid(np.arange(50), np.arange(40))
+    iso = np.stack([gx.ravel() * 2.5, gy.ravel() * 2.5, np.zeros(gx.size)], 1)                    # 2 000 singletons
+    pa = np.stack([np.arange(300) * 2.5, np.full(300, -10.0), np.zeros(300)], 1)
+    pairs = np.concatenate([pa, pa + np.array([0.4, 0.0, 0.0])])                                   # 300 two-point components
+    blob = rng.normal(0.0, 1.5, (1500, 3)) + np.array([-30.0, -30.0, 0.0])
+    pts = np.concatenate([iso, pairs, blob])[rng.permutation(2000 + 600 + 1500)]
+    n = pts.shape[0]
+    A = api.get_affinity_matrix(pts, alpha=1.0, theta=0.0, gamma=0.0)
+    ncomp, comp = connected_components(A, directed=False)
+    groups = api.ncuts(pts, alpha=1.0, theta=0.0, gamma=0.0, T=0.075)
+    st = api.last_stats()
+    lab = ncuts_ref.groups_to_labels(groups, n)
+    assert (lab >= 0).all() and st["unconverged"] == 0
+    # no group straddles two components, and every component of at most 1 % of the points (41) is exactly one group
+    sizes = np.bincount(comp)
+    for g in groups:
+        assert np.unique(comp[g]).size == 1
+    small = np.flatnonzero(sizes <= 0.01 * n)
+    assert small.size >= 2300 and len(groups) >= small.size + 1
+    exp = gpu_model.normalized_cut_model(A, n, np.arange(n), T=0.075)
+    assert len(exp) == len(groups) and ncuts_ref.partitions_equal(lab, ncuts_ref.groups_to_labels(exp, n))
