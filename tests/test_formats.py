@@ -47,3 +47,19 @@ def test_dino_npz_key(tmp_path):
     fm = np.zeros((4, 5, 384), dtype=np.float32)
     np.savez(p, feature_map=fm)
     assert formats.read_dino_npz(p).shape == (4, 5, 384)
+
+
+def test_files_as_the_reference_readers_see_them(tmp_path):
+    """tests/golden/formats/: small files + the arrays the REFERENCE's own readers (kitti_odometry_dataset.py:251-281,
+    :224-249, compiled from the reference file by oracle/gen_format_golden.py) returned from them.  Our readers return the
+    same arrays; our TARL writer reproduces the file byte for byte."""
+    import os
+    from conftest import GOLDEN
+    d = os.path.join(GOLDEN, "formats")
+    exp = np.load(os.path.join(d, "expected.npz"))
+    t = formats.read_tarl_bin(os.path.join(d, "tarl", "000042.bin"))
+    assert t.dtype == np.float32 and np.array_equal(t, exp["tarl_000042"])
+    assert np.array_equal(formats.read_dino_npz(os.path.join(d, "dino", "image_2", "000007.npz")), exp["dino_cam2_000007"])
+    p = tmp_path / "000042.bin"
+    formats.write_tarl_bin(p, exp["tarl_000042"])
+    assert p.read_bytes() == open(os.path.join(d, "tarl", "000042.bin"), "rb").read()

@@ -93,3 +93,20 @@ def test_fullsize_vs_unmodified_oracle(api, name):
     print(name, "groups", ls.size, "vs", rs.size, "ARI", ari, "delta", d, "oracle seconds", meta["affinity_seconds"] + meta["normalized_cut_seconds"])
     assert ari >= ARI_MIN, ari
     assert abs(d["ap"]) <= DAP_MAX and abs(d["S_assoc"]) <= DSASSOC_MAX, d
+
+
+def test_sam_factor_equals_the_reference_function(api):
+    """Row a5 against the reference itself: tests/golden/sam_ref.npz = outputs of the reference's `sam_label_distance`
+    (image_utils.py:64-89; oracle/gen_sam_golden.py).  With alpha = theta = gamma = 0 the affinity IS that factor on the
+    radius mask (ncuts_utils.py:151-156), so the device graph must have the reference's pairs and, to 1e-15 absolute
+    (exp of a ratio of small integers), its values."""
+    import scipy.sparse as sp
+    z = np.load(os.path.join(GOLDEN, "sam_ref.npz"))
+    for c in range(int(z["cases"])):
+        g = {k: z[f"c{c}_{k}"] for k in ("points", "sam", "beta", "radius", "rows", "cols", "factor")}
+        n = g["points"].shape[0]
+        A = api.get_affinity_matrix(g["points"], None, None, alpha=0.0, theta=0.0, gamma=0.0, radius=float(g["radius"]),
+                                    sam=g["sam"], beta=float(g["beta"])).tocoo()
+        ref = sp.csr_matrix((g["factor"], (g["rows"], g["cols"])), shape=(n, n)).tocoo()
+        assert np.array_equal(A.row, ref.row) and np.array_equal(A.col, ref.col), c
+        assert np.abs(A.data - ref.data).max() <= 1e-15, c

@@ -141,6 +141,30 @@ def _sam_ids(n, views, seed):
     return ids
 
 
+def _sam_golden_cases():
+    z = np.load(os.path.join(GOLDEN, "sam_ref.npz"))
+    for c in range(int(z["cases"])):
+        yield {k: z[f"c{c}_{k}"] for k in ("points", "sam", "beta", "radius", "rows", "cols", "factor")}
+
+
+def test_sam_restatement_equals_the_reference_function():
+    """Row a5 pinned: tests/golden/sam_ref.npz holds the outputs of the reference's own `sam_label_distance`
+    (image_utils.py:64-89, compiled from the reference file by oracle/gen_sam_golden.py); the oracle's literal
+    restatement and its sparse form reproduce them exactly (one view, eight views, radius 0.6, a duplicate point, a pair on
+    the radius, a never-seen point)."""
+    from scipy.spatial.distance import cdist
+    for g in _sam_golden_cases():
+        pts, ids, beta, radius = g["points"], g["sam"], float(g["beta"]), float(g["radius"])
+        ld, mask = ncuts_ref.sam_label_distance(ids, cdist(pts, pts), radius, beta)
+        r, c = np.nonzero(mask)
+        assert np.array_equal(r, g["rows"]) and np.array_equal(c, g["cols"])
+        assert np.array_equal(ld[r, c], g["factor"])
+        A = ncuts_ref.affinity_sparse(pts, None, None, alpha=0.0, theta=0.0, gamma=0.0, radius=radius, sam=ids, beta=beta).tocoo()
+        ref = sp.csr_matrix((g["factor"], (g["rows"], g["cols"])), shape=A.shape).tocoo()
+        assert np.array_equal(A.row, ref.row) and np.array_equal(A.col, ref.col)
+        assert np.abs(A.data - ref.data).max() <= 1e-15
+
+
 def test_sam_factor_sparse_equals_literal_dense():
     """Row a5 (beta != 0, never taken by the shipped configs): the sparse restatement of the SAM factor
     equals the literal double loop of image_utils.py:64-89 inside the reference's product order."""
