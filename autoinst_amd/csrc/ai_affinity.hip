@@ -319,19 +319,12 @@ __global__ __launch_bounds__(AI_BLOCK) void k_weights(const int32_t* __restrict_
 // ---- LDS-tiled form of the feature factors (the default when there is no SAM factor and the widths are
 // multiples of 16).  The wave-per-row kernel above gathers E x F x 8 bytes of neighbour feature rows through
 // L2 (5.6 GB for a 200k-point chunk with 96-d features: 32x the algorithmic bytes).  Here a block owns
-// AW_ROWS Morton-consecutive rows; their ~1200 entries touch only ~150-300 DISTINCT columns (consecutive rows
-// share their 27 neighbour cells), so the block collects that set in an LDS hash table, stages the feature rows
-// of the set ONCE per 16-dimension slab (next slab prefetched into registers while the current one is used),
-// and every entry then reads both of its rows from LDS.  Squared distances are summed over the dimensions
-// 0, 1, 2, ... with one fused multiply-add each -- the same order for (i, j) and (j, i), in this path and in its
-// fallback, so the matrix stays bitwise symmetric.
-// tile shape = template parameters <rows per block, lanes per row, entries per lane per round, distinct columns staged at
-// most (else: fallback for the block)>: 16 rows x 16 lanes for the 96-d case, 32 rows x 8 lanes when the 384-d block is present
-// (measured, 200k points: 96-d 0.50 ms vs 0.55 ms; 96-d + 384-d 2.19 ms vs 2.34 ms; the wave-per-row kernel: 0.54 / 4.0 ms)
+// 16 Morton-consecutive rows; their ~600 entries touch only ~200 DISTINCT columns (consecutive rows share their 27
+// neighbour cells), so the block collects that set in an LDS hash table, stages the feature rows of the set ONCE per
+// 16-dimension slab, and every entry then reads its neighbour's slab from LDS.
 #define AW_TABLE 512   // hash slots
-#define AW_SLAB 16     // dimensions per slab (32 measured slower)
+#define AW_SLAB 16     // dimensions per slab
 #define AW_SLAB_LOG 4
-#define AW_STRIDE 17   // padded row of a slab in LDS (doubles)
 
 __device__ __forceinline__ int aw_find(const int32_t* keys, int32_t c) {
   unsigned h = ((unsigned)c * 2654435761u) >> 23;  // 9 bits
@@ -344,16 +337,6 @@ __device__ __forceinline__ int aw_find(const int32_t* keys, int32_t c) {
   return -1;
 }
 
-// sequential squared distance of two feature rows in global memory (fallback path, one thread per entry)
-__device__ __forceinline__ double aw_sqdist_seq(const double* __restrict__ a, const double* __restrict__ b, int dim) {
-  double s = 0.0;
-  for (int k = 0; k < dim; ++k) {
-    const double d = a[k] - b[k];
-    s = fma(d, d, s);
-  }
-  return s;
-}
-
 __device__ __forceinline__ double aw_weight(double dist, double t2, double g2, bool use_t, bool use_d, double alpha, double theta,
                                             double gamma) {
   // factors in the reference's order: tarl * spatial * dino (ncuts_utils.py:151-156; no SAM factor on this path)
@@ -364,20 +347,61 @@ __device__ __forceinline__ double aw_weight(double dist, double t2, double g2, b
   return w;
 }
 
-template <int AW_ROWS, int AW_LPR, int AW_EPL, int AW_MAXD>
-__global__ __launch_bounds__(AI_BLOCK) void k_weights_tiled(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                                            double* __restrict__ val, const int32_t* __restrict__ orig, int64_t n,
-                                                            const double* __restrict__ tarl, int32_t tdim,
-                                                            const uint8_t* __restrict__ notarl, const double* __restrict__ dino,
-                                                            int32_t ddim, double alpha, double theta, double gamma) {
-  static_assert(AW_ROWS * AW_LPR == AI_BLOCK && AW_MAXD < AW_TABLE, "tile shape");
+// Lanes over dimensions: 8 lanes share one entry and each owns two dimensions of the slab, so a 16-lane row group reads
+// two staged rows as two contiguous 128-byte segments (one ds_read_b128 per lane, conflict-free), the row's own values sit
+// in two registers, and the per-entry partial sums stay in registers across the slabs (ACC accumulators = 2 * ACC entry
+// slots per row per round; a slot without an entry points at the row itself and adds zeros).  (Round 2's first tiled
+// form gave every lane its own entries and walked a slab's 16 dimensions sequentially: 64 lanes then read 64 different
+// staged rows at the same dimension -- 16 bank pairs, 2-4-way conflicts -- and the row's own slab was re-read from LDS by
+// all 16 lanes; its hash build counted through one contended LDS atomic and probed every entry twice.  0.50 ms / 2.16 ms
+// per 200k chunk (96-d / 96-d + 384-d) against 0.42 / 1.52 ms for this form; DESIGN section 5 has the phase timings.)
+// Slabs go straight from global memory into LDS (global_load_lds_dwordx4: no staging registers, which is what lets three
+// blocks share a CU).  Summation order of a squared distance: lane m of the 8 sums dimensions
+// 16 s + 2 m, 16 s + 2 m + 1 over the slabs s = 0, 1, ... with one fused multiply-add each; the 8 partials are added as the
+// balanced tree ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7)) (three DPP steps; every node is commutative, so all lanes
+// hold the same bits).  aw_sqdist_tree is the same order for one thread: (i, j) and (j, i) agree bit for bit whichever
+// path computes them.
+__device__ __forceinline__ double aw_sqdist_tree(const double* __restrict__ a, const double* __restrict__ b, int dim) {
+  double p[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int s = 0; s < dim; s += AW_SLAB) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const double d0 = a[s + 2 * m] - b[s + 2 * m];
+      p[m] = fma(d0, d0, p[m]);
+      const double d1 = a[s + 2 * m + 1] - b[s + 2 * m + 1];
+      p[m] = fma(d1, d1, p[m]);
+    }
+  }
+  return ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+}
+__device__ __forceinline__ double aw_group8_sum(double v) {
+  v += ai_dpp<0xB1>(v);   // pairs
+  v += ai_dpp<0x4E>(v);   // quads
+  v += ai_dpp<0x141>(v);  // the two quads of a half row
+  return v;
+}
+
+#define AW_ECAP 2048   // entries of a tile whose hash slot is remembered (more: fallback)
+template <int AW_MAXD, int ACC>
+__global__ __launch_bounds__(AI_BLOCK, 3) void k_weights_lanes(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                               double* __restrict__ val, const int32_t* __restrict__ orig, int64_t n,
+                                                               const double* __restrict__ tarl, int32_t tdim,
+                                                               const uint8_t* __restrict__ notarl, const double* __restrict__ dino,
+                                                               int32_t ddim, double alpha, double theta, double gamma) {
+  constexpr int AW_ROWS = AI_BLOCK / 16;                    // 16 lanes per row
   constexpr int AW_STAGE = (AW_MAXD * AW_SLAB) / AI_BLOCK;  // staged values per thread per slab
-  __shared__ int32_t keys[AW_TABLE];
-  __shared__ int16_t cidx[AW_TABLE];
+  constexpr int EPT = ACC / 8;                              // finished entries per lane (epilogue)
+  static_assert(AW_MAXD < AW_TABLE && ACC % 8 == 0 && AW_SLAB == 16 && AW_TABLE == 2 * AI_BLOCK, "tile shape");
+  // the hash table is dead once every entry knows its staged position: it shares its LDS with the slab buffer
+  __shared__ __attribute__((aligned(16))) double xs[AW_MAXD * AW_SLAB];
+  int32_t* const keys = reinterpret_cast<int32_t*>(xs);
+  uint16_t* const cidx = reinterpret_cast<uint16_t*>(keys + AW_TABLE);
+  static_assert(sizeof(double) * AW_MAXD * AW_SLAB >= AW_TABLE * 6, "the slab buffer holds the hash table");
+  __shared__ uint16_t eslot[AW_ECAP];  // hash slot, then staged position, of every entry of the tile
   __shared__ int32_t corig[AW_MAXD];
   __shared__ int32_t srow[AW_ROWS + 1];
-  __shared__ int32_t s_cnt, s_over;
-  __shared__ double xs[AW_MAXD * AW_STRIDE];
+  __shared__ int32_t wcnt[AI_BLOCK / 64];
+  __shared__ int32_t s_over;
   const int nblk = gridDim.x;
   const int64_t r0 = (int64_t)ai_xcd_task(blockIdx.x, nblk) * AW_ROWS;
   if (r0 >= n) return;
@@ -385,34 +409,65 @@ __global__ __launch_bounds__(AI_BLOCK) void k_weights_tiled(const int32_t* __res
   const int tid = threadIdx.x;
   const bool use_t = (theta != 0.0) && tarl != nullptr;
   const bool use_d = (gamma != 0.0) && dino != nullptr;
-  for (int i = tid; i < AW_TABLE; i += AI_BLOCK) keys[i] = -1;
+  keys[tid] = -1;
+  keys[tid + AI_BLOCK] = -1;
   if (tid <= nrows) srow[tid] = rowptr[r0 + tid];
-  if (tid == 0) {
-    s_cnt = 0;
-    s_over = 0;
-  }
+  if (tid == 0) s_over = 0;
   __syncthreads();
   const int32_t e0 = srow[0], e1 = srow[nrows];
-  // ---- distinct columns of the tile (every row is its own neighbour, so the rows themselves are in the set)
-  for (int32_t e = e0 + tid; e < e1; e += AI_BLOCK) {
-    const int32_t c = col[e];
-    unsigned h = ((unsigned)c * 2654435761u) >> 23;
-    bool done = false;
-    for (int i = 0; i < AW_TABLE && !done; ++i) {
-      const int32_t old = atomicCAS(&keys[h], -1, c);
-      if (old == -1) {
-        if (atomicAdd(&s_cnt, 1) >= AW_MAXD) s_over = 1;
-        done = true;
-      } else if (old == c) {
-        done = true;
-      } else {
-        h = (h + 1) & (AW_TABLE - 1);
+  // ---- distinct columns of the tile (every row is its own neighbour, so the rows themselves are in the set): open
+  // addressing in LDS; the slot an entry ended in is remembered, so that it is probed once
+  if (e1 - e0 > AW_ECAP) {
+    if (tid == 0) s_over = 1;
+  } else {
+    for (int32_t e = e0 + tid; e < e1; e += AI_BLOCK) {
+      const int32_t c = col[e];
+      unsigned h = ((unsigned)c * 2654435761u) >> 23;
+      bool done = false;
+      for (int i = 0; i < AW_TABLE && !done; ++i) {
+        const int32_t old = atomicCAS(&keys[h], -1, c);
+        if (old == -1 || old == c) {
+          done = true;
+        } else {
+          h = (h + 1) & (AW_TABLE - 1);
+        }
       }
+      if (!done) s_over = 1;
+      eslot[e - e0] = (uint16_t)h;
     }
-    if (!done) s_over = 1;
   }
   __syncthreads();
-  if (s_over) {
+  // ---- number the occupied slots (ballot + prefix over the four waves: no counter to contend for)
+  int nd = 0;
+  {
+    const int32_t k0 = keys[2 * tid], k1 = keys[2 * tid + 1];
+    const int mine = (k0 >= 0) + (k1 >= 0);
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o, 64);
+      if ((tid & 63) >= o) incl += v;
+    }
+    if ((tid & 63) == 63) wcnt[tid >> 6] = incl;
+    __syncthreads();
+    int pos = incl - mine;
+#pragma unroll
+    for (int w = 0; w < AI_BLOCK / 64; ++w) {
+      if (w < (tid >> 6)) pos += wcnt[w];
+      nd += wcnt[w];
+    }
+    if (nd <= AW_MAXD && !s_over) {
+      if (k0 >= 0) {
+        cidx[2 * tid] = (uint16_t)pos;
+        corig[pos++] = orig[k0];
+      }
+      if (k1 >= 0) {
+        cidx[2 * tid + 1] = (uint16_t)pos;
+        corig[pos] = orig[k1];
+      }
+    }
+  }
+  if (nd > AW_MAXD || s_over) {
     // ---- fallback (dense clouds: more than AW_MAXD distinct neighbours): one thread per entry, rows from global memory
     for (int32_t e = e0 + tid; e < e1; e += AI_BLOCK) {
       int lo = 0, hi = nrows - 1;
@@ -423,96 +478,96 @@ __global__ __launch_bounds__(AI_BLOCK) void k_weights_tiled(const int32_t* __res
       const int64_t i = r0 + lo, j = col[e];
       const int64_t oi = orig[i], oj = orig[j];
       double t2 = 0.0, g2 = 0.0;
-      if (use_t && !(notarl[i] || notarl[j])) t2 = aw_sqdist_seq(tarl + oi * tdim, tarl + oj * tdim, tdim);
-      if (use_d) g2 = aw_sqdist_seq(dino + oi * ddim, dino + oj * ddim, ddim);
+      if (use_t && !(notarl[i] || notarl[j])) t2 = aw_sqdist_tree(tarl + oi * tdim, tarl + oj * tdim, tdim);
+      if (use_d) g2 = aw_sqdist_tree(dino + oi * ddim, dino + oj * ddim, ddim);
       val[e] = aw_weight(val[e], t2, g2, use_t, use_d, alpha, theta, gamma);
     }
     return;
   }
-  // ---- compact the occupied slots: cidx[slot] = position in the staged list, corig[position] = caller's row id
   __syncthreads();
-  if (tid == 0) s_cnt = 0;
+  for (int i = tid; i < e1 - e0; i += AI_BLOCK) eslot[i] = cidx[eslot[i]];  // hash slot -> staged position
   __syncthreads();
-  for (int i = tid; i < AW_TABLE; i += AI_BLOCK) {
-    const int32_t k = keys[i];
-    if (k >= 0) {
-      const int pos = atomicAdd(&s_cnt, 1);
-      cidx[i] = (int16_t)pos;
-      corig[pos] = orig[k];
-    }
-  }
-  __syncthreads();
-  const int nd = s_cnt;
-  const int l = tid & (AW_LPR - 1), g = tid / AW_LPR;  // lane in the row group, row of the tile
+  const int l = tid & 15, g = tid >> 4;  // lane in the row group, row of the tile
+  const int h = l >> 3, m = l & 7;       // entry slot of the pair in flight, lane of the 8 that share an entry
   const bool rlive = g < nrows;
   const int32_t p0 = rlive ? srow[g] : 0, p1 = rlive ? srow[g + 1] : 0;
   int maxlen = 0;
   for (int r = 0; r < nrows; ++r) maxlen = max(maxlen, srow[r + 1] - srow[r]);  // block-uniform
-  const int ci = rlive ? (int)cidx[aw_find(keys, (int32_t)(r0 + g))] : 0;
+  const uint32_t ci = rlive ? (uint32_t)cidx[aw_find(keys, (int32_t)(r0 + g))] : 0u;
   const bool nti = (use_t && rlive) ? (notarl[r0 + g] != 0) : false;
-  const int nts = use_t ? tdim / AW_SLAB : 0, nds = use_d ? ddim / AW_SLAB : 0;
-  const int nslab = nts + nds;
-  for (int base = 0; base < maxlen; base += AW_LPR * AW_EPL) {
-    int cj[AW_EPL];
-    double at[AW_EPL], ag[AW_EPL];
+  for (int base = 0; base < maxlen; base += 2 * ACC) {
+    const int rounds = min(ACC, (maxlen - base + 1) >> 1);  // block-uniform number of entry pairs in this round
+    // staged position of entry slot 2 * it + h of this row, two per register; a slot without an entry points at the row
+    // itself (distance 0: adds nothing)
+    // (kept as the BYTE offset of this lane's two dimensions in the slab buffer)
+    uint32_t cj2[ACC];
 #pragma unroll
-    for (int q = 0; q < AW_EPL; ++q) {
-      const int32_t e = p0 + base + l + q * AW_LPR;
-      cj[q] = (e < p1) ? (int)cidx[aw_find(keys, col[e])] : -1;
-      at[q] = 0.0;
-      ag[q] = 0.0;
+    for (int it = 0; it < ACC; ++it) {
+      uint32_t c = ci;
+      if (it < rounds) {
+        const int32_t e = p0 + base + 2 * it + h;
+        if (e < p1) c = eslot[e - e0];
+      }
+      cj2[it] = c * (AW_SLAB * 8) + 16 * m;
     }
-    double st[AW_STAGE];
-    auto fetch = [&](int sl) {
-      const bool is_t = sl < nts;
-      const double* f = is_t ? tarl : dino;
-      const int64_t dim = is_t ? tdim : ddim;
-      const int off = (is_t ? sl : sl - nts) * AW_SLAB;
+    double acc[ACC];
+    // one feature block: squared distances of the round's entries, finished sums handed to lane (it & 7) of the 8
+    auto run = [&](const double* __restrict__ f, int64_t dim, double (&fin)[EPT]) {
+      // one slab of the tile's distinct rows straight into LDS (global_load_lds_dwordx4: 16 bytes per lane, a wave's 64
+      // lanes fill 1 KB = 8 staged rows; no staging registers): piece p = (row p >> 3, dimensions 2 (p & 7), +1)
+      auto stage = [&](int sl) {
 #pragma unroll
-      for (int i = 0; i < AW_STAGE; ++i) {
-        const int p = tid + AI_BLOCK * i;
-        const int c = p >> AW_SLAB_LOG, k = p & (AW_SLAB - 1);
-        st[i] = (c < nd) ? f[(int64_t)corig[c] * dim + off + k] : 0.0;
-      }
-    };
-    if (nslab > 0) fetch(0);
-    for (int sl = 0; sl < nslab; ++sl) {
-      __syncthreads();  // the previous slab has been consumed
+        for (int i = 0; i < AW_STAGE / 2; ++i) {
+          const int p = tid + AI_BLOCK * i;
+          const int c = min(p >> 3, nd - 1);
+          const double* src = f + (int64_t)corig[c] * dim + sl * AW_SLAB + 2 * (p & 7);
+          double* dst = xs + 2 * ((tid & ~63) + AI_BLOCK * i);  // wave-uniform; lane l lands at dst + 2 l
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+      };
 #pragma unroll
-      for (int i = 0; i < AW_STAGE; ++i) {
-        const int p = tid + AI_BLOCK * i;
-        const int c = p >> AW_SLAB_LOG, k = p & (AW_SLAB - 1);
-        if (c < nd) xs[c * AW_STRIDE + k] = st[i];
-      }
-      __syncthreads();
-      if (sl + 1 < nslab) fetch(sl + 1);  // in flight while this slab is used
-      if (rlive) {
-        double fi[AW_SLAB];
+      for (int it = 0; it < ACC; ++it) acc[it] = 0.0;
+      const int nslab = (int)(dim >> AW_SLAB_LOG);
+      for (int sl = 0; sl < nslab; ++sl) {
+        __syncthreads();  // the previous slab (or the hash table) has been consumed
+        stage(sl);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (rlive) {
+          const double2 fi = *reinterpret_cast<const double2*>(&xs[ci * AW_SLAB + 2 * m]);
 #pragma unroll
-        for (int k = 0; k < AW_SLAB; ++k) fi[k] = xs[ci * AW_STRIDE + k];
-        const bool is_t = sl < nts;
-#pragma unroll
-        for (int q = 0; q < AW_EPL; ++q) {
-          if (cj[q] >= 0) {
-            const double* b = &xs[cj[q] * AW_STRIDE];
-            double s = is_t ? at[q] : ag[q];
-#pragma unroll
-            for (int k = 0; k < AW_SLAB; ++k) {
-              const double d = fi[k] - b[k];
-              s = fma(d, d, s);
+          for (int it = 0; it < ACC; ++it) {
+            if (it < rounds) {
+              const uint32_t off = cj2[it];
+              const double2 b = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(xs) + off);
+              const double d0 = fi.x - b.x;
+              acc[it] = fma(d0, d0, acc[it]);
+              const double d1 = fi.y - b.y;
+              acc[it] = fma(d1, d1, acc[it]);
             }
-            if (is_t) at[q] = s; else ag[q] = s;
           }
         }
       }
-    }
 #pragma unroll
-    for (int q = 0; q < AW_EPL; ++q) {
-      const int32_t e = p0 + base + l + q * AW_LPR;
+      for (int it = 0; it < ACC; ++it) {
+        const double tot = aw_group8_sum(acc[it]);
+        if ((it & 7) == m) fin[it >> 3] = tot;
+      }
+    };
+    double t2[EPT], g2[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) t2[k] = g2[k] = 0.0;
+    if (use_t) run(tarl, tdim, t2);
+    if (use_d) run(dino, ddim, g2);
+    // lane m of entry slot h finishes the entries 2 * (8 k + m) + h of the round
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int32_t e = p0 + base + 2 * (8 * k + m) + h;
       if (e < p1) {
-        double t2 = at[q];
-        if (use_t && (nti || notarl[col[e]] != 0)) t2 = 0.0;
-        val[e] = aw_weight(val[e], t2, ag[q], use_t, use_d, alpha, theta, gamma);
+        double t = t2[k];
+        if (use_t && (nti || notarl[col[e]] != 0)) t = 0.0;
+        val[e] = aw_weight(val[e], t, g2[k], use_t, use_d, alpha, theta, gamma);
       }
     }
   }
@@ -734,16 +789,10 @@ extern "C" int ai_affinity_build_sam(ai_ctx* ctx, const double* xyz, int64_t n, 
     static const int force_rowwise = getenv("AI_WEIGHTS_ROWWISE") ? atoi(getenv("AI_WEIGHTS_ROWWISE")) : 0;
     const bool tiled = !force_rowwise && (has_t || has_d) && d_sam == nullptr && (!has_t || tarl_dim % AW_SLAB == 0) && (!has_d || dino_dim % AW_SLAB == 0);
     if (tiled) {
-      // LDS-tiled: every distinct neighbour's feature row is read once per 32-row tile
-      if (has_d) {
-        hipLaunchKernelGGL((k_weights_tiled<32, 8, 8, 384>), dim3((unsigned)((n + 31) / 32)), dim3(AI_BLOCK), 0, st, (const int32_t*)A->rowptr,
-                           (const int32_t*)A->col, A->val, (const int32_t*)A->orig, n, d_tarl, tarl_dim, (const uint8_t*)notarl.p, d_dino, dino_dim,
-                           alpha, theta, gamma);
-      } else {
-        hipLaunchKernelGGL((k_weights_tiled<16, 16, 4, 256>), dim3((unsigned)((n + 15) / 16)), dim3(AI_BLOCK), 0, st, (const int32_t*)A->rowptr,
-                           (const int32_t*)A->col, A->val, (const int32_t*)A->orig, n, d_tarl, tarl_dim, (const uint8_t*)notarl.p, d_dino, dino_dim,
-                           alpha, theta, gamma);
-      }
+      // LDS-tiled: every distinct neighbour's feature row is read once per 16-row tile
+      hipLaunchKernelGGL((k_weights_lanes<256, 32>), dim3((unsigned)((n + 15) / 16)), dim3(AI_BLOCK), 0, st, (const int32_t*)A->rowptr,
+                         (const int32_t*)A->col, A->val, (const int32_t*)A->orig, n, d_tarl, tarl_dim, (const uint8_t*)notarl.p, d_dino, dino_dim,
+                         alpha, theta, gamma);
     } else {
     // wave per row (SAM factor, widths that are not multiples of 16): the row's own features stay in registers
     // when the width is the reference's (96-d TARL, 384-d DINO);
