@@ -256,6 +256,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--in-flight", type=int, default=4, help="host threads (contexts) per GPU")
     ap.add_argument("--batch", type=int, default=6, help="chunks per batched call (root segments of one frontier)")
+    ap.add_argument("--batches", type=int, default=0, help="batched calls per GPU per step (default: one per host thread)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-inputs", action="store_true", help="skip the pinned-host-input leg (value_host_inputs)")
     ap.add_argument("--dry", action="store_true", help="CPU-only rehearsal of the multi-rank plumbing (gloo), no compute")
@@ -289,31 +290,34 @@ def main():
 
     K = max(1, args.in_flight)   # host threads per rank, each with its own context (HIP streams + workspace)
     B = max(1, args.batch)       # chunks per ai_ncut_batch call: root segments of one frontier
+    M = args.batches if args.batches > 0 else K   # batched calls per step, taken from one queue by the K threads
     dev = torch.device("cuda", local_rank)
     ctxs = [api.Context(local_rank) for _ in range(K)]
-    # The world's chunk list (world*K*B chunks of N_POINTS points) is dealt to the ranks by the LPT rule the
-    # map driver uses; chunk c's input is the synthetic chunk of seed c mod K*B, so every rank holds the same
-    # K*B different inputs resident in HBM and the per-GPU work is exactly fixed as N grows (weak scaling;
+    # The world's chunk list (world*M*B chunks of N_POINTS points) is dealt to the ranks by the LPT rule the
+    # map driver uses; chunk c's input is the synthetic chunk of seed c mod M*B, so every rank holds the same
+    # M*B different inputs resident in HBM and the per-GPU work is exactly fixed as N grows (weak scaling;
     # one chunk costs 26-59 ms depending on its seed).
-    my_chunks = sharding.lpt_assign([N_POINTS] * (world * K * B), world)[rank]
-    assert len(my_chunks) == K * B
+    my_chunks = sharding.lpt_assign([N_POINTS] * (world * M * B), world)[rank]
+    assert len(my_chunks) == M * B
     data, host = [], []
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=4) as gen:   # set-up only: ~2 s of NumPy per chunk
-        for ch in gen.map(lambda c: synth.synthetic_chunk(N_POINTS, seed=c % (K * B), tarl=True), my_chunks):
+        for ch in gen.map(lambda c: synth.synthetic_chunk(N_POINTS, seed=c % (M * B), tarl=True), my_chunks):
             data.append((torch.from_numpy(ch["points"]).to(dev), torch.from_numpy(ch["tarl"]).to(dev)))
             if not args.no_host_inputs:
                 host.append((torch.from_numpy(ch["points"]).pin_memory(), torch.from_numpy(ch["tarl"]).pin_memory()))
     torch.cuda.synchronize()
 
-    def one_batch(k, profile=False, only_first=False, from_host=False):
+    def one_batch(k, profile=False, only_first=False, from_host=False, w=None):
+        # batch k of the rank's M batches, run by host thread w on that thread's context
+        ctx = ctxs[k % K if w is None else w]
         sl = slice(k * B, (k + 1) * B)
         if from_host:
             mine = [(p.numpy(), f.numpy()) for p, f in host[sl]]
         else:
             mine = data[sl]
         mine = mine[: 1 if only_first else B]
-        graphs = [api.build_affinity(p, f, alpha=CFG["alpha"], theta=CFG["theta"], gamma=CFG["gamma"], ctx=ctxs[k]) for p, f in mine]
+        graphs = [api.build_affinity(p, f, alpha=CFG["alpha"], theta=CFG["theta"], gamma=CFG["gamma"], ctx=ctx) for p, f in mine]
         try:
             if len(graphs) == 1:
                 lab, ng, st = api.ncuts_labels(graphs[0], N_POINTS, CFG["T"], time_spmv=profile)
@@ -328,37 +332,43 @@ def main():
 
     import queue
     import threading
-    jobs = [queue.Queue() for _ in range(K)]   # per worker: (number of batches, kwargs) (None = exit)
-    qs = [queue.Queue() for _ in range(K)]     # per worker: results, one per batch
+    # The K host threads live for the whole run (warm-up, timed steps, latency and profile passes) and take batches from ONE
+    # queue, as workers of a map driver take chunks: a batch costs 160-260 ms depending on its six chunks, so a fixed
+    # batch-per-thread deal would leave the faster threads idle at the end of the timed region.
+    work = queue.Queue()       # (step, batch, kwargs); None = exit
+    results = {}               # (step, batch) -> result
+    cv = threading.Condition()
 
-    def worker(k):
-        # the K host threads live for the whole run (warm-up, timed steps, latency and profile passes)
+    def worker(w):
         while True:
-            job = jobs[k].get()
+            job = work.get()
             if job is None:
                 return
-            n, kw = job
-            for _ in range(n):
-                try:
-                    qs[k].put(one_batch(k, **kw))
-                except BaseException as e:  # surface the failure in the consuming thread
-                    qs[k].put(e)
-                    break
+            step, k, kw = job
+            try:
+                r = one_batch(k, w=w, **kw)
+            except BaseException as e:  # surface the failure in the consuming thread
+                r = e
+            with cv:
+                results[(step, k)] = r
+                cv.notify_all()
 
-    workers = [threading.Thread(target=worker, args=(k,), daemon=True) for k in range(K)]
+    workers = [threading.Thread(target=worker, args=(w,), daemon=True) for w in range(K)]
     for t in workers:
         t.start()
 
     def run_steps(nsteps, **kw):
-        """`nsteps` steps: every host thread pushes `nsteps` batches back to back (the library calls release
-        the GIL, so the K batches really are in flight together, and a thread does not wait for the others
-        between steps); this thread takes each step's K results as they complete and (N > 1) gathers that
-        step's label arrays to rank 0.  Returns the last step's results."""
-        for k in range(K):
-            jobs[k].put((nsteps, kw))
+        """`nsteps` steps = nsteps * M batches, queued at once: the library calls release the GIL, so K batches really are
+        in flight together, and a thread does not wait for the others between steps.  This thread takes each step's M
+        results as they complete and (N > 1) gathers that step's label arrays to rank 0.  Returns the last step's results."""
+        for s_ in range(nsteps):
+            for k in range(M):
+                work.put((s_, k, kw))
         last = None
-        for _ in range(nsteps):
-            res = [q.get() for q in qs]
+        for s_ in range(nsteps):
+            with cv:
+                cv.wait_for(lambda: all((s_, k) in results for k in range(M)))
+                res = [results.pop((s_, k)) for k in range(M)]
             for r in res:
                 if isinstance(r, BaseException):
                     if world > 1:
@@ -367,7 +377,7 @@ def main():
                         sys.stderr.flush()
                         os._exit(1)
                     raise r
-            local = {my_chunks[k * B + b]: res[k][0][b] for k in range(K) for b in range(B)}
+            local = {my_chunks[k * B + b]: res[k][0][b] for k in range(M) for b in range(B)}
             merged = sharding.gather_labels(local, device=dev) if world > 1 else local
             last = (res, merged)
         return last
@@ -409,7 +419,7 @@ def main():
     res_ov, _ = run_steps(1, profile="clock")
     t_ov = time.perf_counter() - t_ov0
     ov = {"launches": 0, "bytes": 0.0, "ms": 0.0}
-    for k in range(K):
+    for k in range(M):
         s = res_ov[k][2]
         ov["launches"] += int(s["lanczos_steps"])
         ov["bytes"] += spmv_bytes(int(s["spmv_rows"]), int(s["spmv_nnz"]), int(s["lanczos_steps"]))
@@ -425,14 +435,14 @@ def main():
     _, _, stp, _ = one_batch(0, profile="clock")
     _, _, stp_ev, _ = one_batch(0, profile="events")   # cross-check: HIP start/stop events on every dispatch
     barrier()
-    for k in range(K):
-        jobs[k].put(None)
+    for _ in range(K):
+        work.put(None)
     for t in workers:
         t.join()
 
     free_b, total_b = torch.cuda.mem_get_info(dev)
     if rank == 0:
-        assert merged is not None and sorted(merged) == list(range(world * K * B)) and all(v.shape[0] == N_POINTS for v in merged.values())
+        assert merged is not None and sorted(merged) == list(range(world * M * B)) and all(v.shape[0] == N_POINTS for v in merged.values())
         launches = int(stp["lanczos_steps"])
         b = spmv_bytes(int(stp["spmv_rows"]), int(stp["spmv_nnz"]), launches)
         ach_solo = b / (stp["ms_spmv"] * 1e-3) / 1e9 if stp["ms_spmv"] > 0 else 0.0
@@ -442,7 +452,7 @@ def main():
         traffic, traffic_src = pmc_traffic(B)
         out = {
             "metric": "chunks/sec (200k-pt TARL+Spatial NCuts chunk: affinity build + recursive normalized cut)",
-            "value": world * K * B * args.steps / elapsed,
+            "value": world * M * B * args.steps / elapsed,
             "unit": "chunks/sec",
             "n_gpus": world,
             "steps": args.steps,
@@ -456,10 +466,10 @@ def main():
             "rccl_ranks": dist.get_world_size() if world > 1 else 1,
             "backend": dist.get_backend() if world > 1 else "none",
             "config": {"workload": "configs[1]: single 200k-point surface chunk, TARL(96-d)+Spatial affinities, "
-                                   f"alpha=1 theta=0.5 T=0.03; per GPU per step {K} host threads x {B} chunks batched into one frontier",
-                       "n_points": N_POINTS, "nnz": int(nnz), "chunks_per_step": world * K * B, "threads_per_gpu": K, "chunks_per_batch": B,
+                                   f"alpha=1 theta=0.5 T=0.03; per GPU per step {M} batched calls of {B} chunks (one frontier each) taken from a queue by {K} host threads",
+                       "n_points": N_POINTS, "nnz": int(nnz), "chunks_per_step": world * M * B, "threads_per_gpu": K, "chunks_per_batch": B, "batches_per_step": M,
                        "parallelism": f"chunk-dp{world}"},
-            "value_host_inputs": (world * K * B * host_steps / elapsed_host) if elapsed_host else None,
+            "value_host_inputs": (world * M * B * host_steps / elapsed_host) if elapsed_host else None,
             "host_inputs_note": "same loop, points + features in pinned host memory (159 MB per chunk), copied by the library on the context's stream"
                                 if elapsed_host else None,
             "hbm_in_use_gb": (total_b - free_b) / 1e9,   # inputs + K workspaces (arena, cached graph buffers) + torch
