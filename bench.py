@@ -304,7 +304,7 @@ def main():
     with ThreadPoolExecutor(max_workers=4) as gen:   # set-up only: ~2 s of NumPy per chunk
         for ch in gen.map(lambda c: synth.synthetic_chunk(N_POINTS, seed=c % (M * B), tarl=True), my_chunks):
             data.append((torch.from_numpy(ch["points"]).to(dev), torch.from_numpy(ch["tarl"]).to(dev)))
-            if not args.no_host_inputs:
+            if not args.no_host_inputs and world == 1:   # the host-input leg is an N = 1 measurement
                 host.append((torch.from_numpy(ch["points"]).pin_memory(), torch.from_numpy(ch["tarl"]).pin_memory()))
     torch.cuda.synchronize()
 
@@ -509,7 +509,7 @@ def main():
                 "aggregate_gbps": ach_agg,
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only: the other ranks would sit in the final barrier
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
