@@ -19,7 +19,7 @@ so the world's chunk list is dealt to the ranks by `sharding.lpt_assign` and the
 collective ("weak" scaling: the same number of chunks per rank per step).
 
 Rank 0 prints ONE JSON line.
-* `roofline` is for the dominant kernel (the fused Lanczos SpMV, `k_lz_spmv_x`): algorithmic bytes of its
+* `roofline` is for the dominant kernel (the fused Lanczos SpMV, `k_lz_spmv_q`): algorithmic bytes of its
   launches / their summed duration, measured live: every launch stamps its own span on the device clock (this
   agrees with rocprofv3's per-kernel average; HIP start/stop events on every dispatch of the library's stream
   are reported beside it for the solo regime -- they serialise the queue and read 10-30 % longer).  Two regimes are measured and both are reported: `frac_solo` (one batched call alone on
@@ -486,7 +486,7 @@ def main():
             "groups": int(ng),
             "unconverged": int(st["unconverged"]),
             "roofline": {
-                "kernel": "k_lz_spmv_x",
+                "kernel": "k_lz_spmv_q",
                 "bound": "hbm",
                 "achieved": ach_ov,
                 "peak": HBM_PEAK_GBPS,

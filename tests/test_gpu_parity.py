@@ -237,9 +237,10 @@ def _dense_blobs(n, spread, seed):
 
 
 @pytest.mark.parametrize("n,spread", [(2500, 0.9), (3000, 0.45), (6000, 2.0)])
-def test_staged_gather_equals_plain_gather_bitwise(api, monkeypatch, n, spread):
-    """The SpMV with LDS-staged distinct columns and the plain global-memory gather are the same
-    arithmetic: identical labels and residuals.  The dense cases exceed the encoder's
+def test_staged_gather_equals_plain_gather(api, monkeypatch, n, spread):
+    """The SpMV with LDS-staged distinct columns (entries taken as aligned quads) and the plain global-memory gather
+    (entries strided over the lanes) add a row's products in different orders: identical labels, residuals equal to
+    rounding.  The dense cases exceed the encoder's
     per-task capacity (4096 entries / 1024 distinct columns), so their tasks take the plain path inside
     the staged kernel; the sparse case is fully encoded."""
     pts = _dense_blobs(n, spread, n)
@@ -254,7 +255,8 @@ def test_staged_gather_equals_plain_gather_bitwise(api, monkeypatch, n, spread):
     g.free()
     assert n0 == n1 >= 2 and np.array_equal(l0, l1)
     # (lanczos_steps counts launches, including the few issued past convergence while a check was in flight)
-    assert s0["lanczos_solves"] == s1["lanczos_solves"] > 0 and s0["max_resid"] == s1["max_resid"] and s0["unconverged"] == 0
+    assert s0["lanczos_solves"] == s1["lanczos_solves"] > 0 and s0["unconverged"] == s1["unconverged"] == 0
+    assert abs(s0["max_resid"] - s1["max_resid"]) <= 1e-6 * s1["max_resid"]
     if spread < 1.5:   # (T = 0.5 on the sparse blob pair recurses into near-tie cuts: no model comparison there)
         exp = gpu_model.normalized_cut_model(A, n, np.arange(n), T=0.5)
         lab = np.empty(n, np.int64)
