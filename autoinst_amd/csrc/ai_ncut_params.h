@@ -1,6 +1,8 @@
 // Tile shapes and capacities shared by the kernels and the host driver of the recursion (ai_ncut.hip, ai_eigs.hip).
 #pragma once
-#define AI_FINE_ROWS 32      // rows per block in the 16-lanes-per-row kernels (2 rows in flight per lane group; 16 / 128 measured slower, 64 equal in throughput and 7 % slower for one chunk)
+#ifndef AI_FINE_ROWS
+#define AI_FINE_ROWS 32      // rows per block in the 16-lanes-per-row kernels (2 rows in flight per lane group; 16 / 128 measured slower, 64: 20.6 vs 17.4 us per launch on a whole 200k graph, 111 vs 121 chunks/s with the quad kernel)
+#endif
 #define AI_COARSE_ROWS 512   // rows per block in the thread-per-row kernels (256 / 1024 measured within 2 %)
 #define AI_ROW_ILP (AI_FINE_ROWS / (AI_BLOCK / AI_LPR))
 #define AI_SLAB_VECS 32      // Lanczos vectors per HBM slab
