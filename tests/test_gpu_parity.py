@@ -44,6 +44,32 @@ def test_affinity_matches_golden(api, name):
     assert np.all(B.diagonal() == 1.0)
 
 
+@pytest.mark.parametrize("tdim,ddim", [(96, 0), (32, 48), (0, 64), (112, 16)])
+def test_feature_factors_tiled_and_fallback_tiles_in_one_graph(api, tdim, ddim):
+    """`k_weights_lanes`: a sparse sheet (tiles staged in LDS), a dense blob inside it (tiles with more than 256 distinct
+    neighbours or more than 2048 entries take the per-entry fallback) and rows of more than 64 entries (second round of a
+    tile) in ONE graph, feature widths that are multiples of 16 but not the reference's: values equal the oracle's to 1e-12,
+    and (i, j) == (j, i) bit for bit whichever path computed them."""
+    rng = np.random.default_rng(100 + tdim + ddim)
+    sheet = np.c_[rng.uniform(-12, 12, (5000, 2)), rng.normal(0, 0.05, 5000)]
+    blob = rng.normal(0, 0.35, (1500, 3)) + np.array([2.0, -3.0, 0.0])
+    mid = rng.normal(0, 0.8, (1500, 3)) + np.array([-5.0, 4.0, 0.0])
+    pts = np.concatenate([sheet, blob, mid])
+    n = pts.shape[0]
+    tarl = rng.normal(0, 0.4, (n, tdim)) if tdim else None
+    if tarl is not None:
+        tarl[::9] = 0.0
+    dino = rng.normal(0, 0.3, (n, ddim)) if ddim else None
+    kw = dict(alpha=1.0, theta=0.5 if tdim else 0.0, gamma=0.1 if ddim else 0.0)
+    A = api.get_affinity_matrix(pts, tarl, dino, **kw)
+    B = ncuts_ref.affinity_sparse(pts, tarl, dino, **kw)
+    deg = np.diff(A.indptr)
+    assert deg.max() > 400 and (deg > 64).sum() > 500 and (deg < 40).sum() > 2000   # all three regimes are present
+    assert np.array_equal(A.indptr, B.indptr) and np.array_equal(A.indices, B.indices)
+    assert (np.abs(A.data - B.data) / B.data).max() <= 1e-12
+    assert abs(A - A.T).max() == 0.0 and np.all(A.diagonal() == 1.0)
+
+
 @pytest.mark.parametrize("name", ["g2_multicomp_spatial", "g6_connected_tarl"])
 def test_lsym_apply_matches_scipy(api, name):
     z, A, _, _ = load(name)
