@@ -434,6 +434,20 @@ def main():
     ng = ngs1[0]
     _, _, stp, _ = one_batch(0, profile="clock")
     _, _, stp_ev, _ = one_batch(0, profile="events")   # cross-check: HIP start/stop events on every dispatch
+    # a plain device-to-device copy on the same box (quote the roofline against a measured stream number too):
+    # 1 GiB read + 1 GiB written per repeat, alone on the device
+    src = torch.empty(1 << 27, dtype=torch.float64, device=dev).fill_(1.0)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    copy_gbps = 10 * 2 * src.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del src, dst
     barrier()
     for _ in range(K):
         work.put(None)
@@ -496,6 +510,7 @@ def main():
                 "frac_overlapped": ach_ov / HBM_PEAK_GBPS,
                 "frac_solo": ach_solo / HBM_PEAK_GBPS,
                 "frac_aggregate": ach_agg / HBM_PEAK_GBPS,
+                "device_copy_gbps": copy_gbps,   # torch d2d copy of 1 GiB (read + write bytes), same box, alone
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "overlapped": {"launches": ov["launches"], "avg_launch_us": 1e3 * ov["ms"] / max(ov["launches"], 1),
