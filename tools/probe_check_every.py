@@ -1,5 +1,5 @@
 import sys, time, json, torch
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from autoinst_amd import ncuts_api as api, synth
 dev = torch.device("cuda", 0)
 ch = synth.synthetic_chunk(200_000, 0, tarl=True)
