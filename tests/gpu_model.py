@@ -158,7 +158,7 @@ def split_components(ncomp, comp):
     remainder (``:56-59``): the components are peeled off one at a time, each continuing on its own.  The
     reference stops peeling when the remainder is no longer eligible (<= 1 % of the chunk, ``:39-40``) and emits
     that ONE remainder as a group; which components are left in it cannot be reproduced (it is a function of
-    SuperLU's round-off, see ``tools/fullsize_delta.py``), so the device -- and this model -- let every component
+    SuperLU's round-off, see ``tests/tools/fullsize_delta.py``), so the device -- and this model -- let every component
     continue on its own.  Children come in the order of the components' first rows.
     """
     n = comp.shape[0]

@@ -124,7 +124,7 @@ def test_connected_solves_of_model_and_scipy_lead_to_the_same_cuts(n):
     gives EXACTLY the partition (and group order) of the device algorithm's model, up to BASELINE.json's full
     200k-point chunk (the GPU suite shows device == model on the same graph): every connected solve leads to the
     same cut.  What is left between device and reference is the one <= 1 % remainder per disconnected segment that
-    the reference does not split (tests/golden/full_*.npz, tools/fullsize_delta.py)."""
+    the reference does not split (tests/golden/full_*.npz, tests/tools/fullsize_delta.py)."""
     from autoinst_amd import synth
     T = 0.03
     ch = synth.synthetic_chunk(n, 0, tarl=True)

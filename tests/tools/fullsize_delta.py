@@ -3,11 +3,11 @@ group, tests/test_gpu_fullsize.py) is from the UNMODIFIED oracle on the full-siz
 made by oracle/gen_fullsize.py), and how far the oracle is from ITSELF when ARPACK starts in another state
 (the `_w3` / `_w7` fixtures).
 
-    python tools/fullsize_delta.py [pattern]   -> one JSON line per fixture (profiles/r02_fullsize_delta.jsonl)
+    python tests/tools/fullsize_delta.py [pattern]   -> one JSON line per fixture (profiles/r02_fullsize_delta.jsonl)
 """
 import glob, json, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from autoinst_amd import synth
 from oracle import metrics_ref, ncuts_ref

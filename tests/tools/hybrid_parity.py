@@ -6,11 +6,11 @@ recursion amounts to there, one component per eigsh call: gpu_model.split_compon
 algorithm, Lanczos on connected segments) then every connected solve led to the same cut, and the
 only source of oracle-vs-device differences is SciPy's arbitrary choice in the null space.
 
-    python tools/hybrid_parity.py N [tarl|spatial] [seed]
+    python tests/tools/hybrid_parity.py N [tarl|spatial] [seed]
 """
 import sys, time, json
 import numpy as np
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import os; _R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, _R); sys.path.insert(0, os.path.join(_R, "tests"))
 from oracle import ncuts_ref
 from autoinst_amd import synth
 import gpu_model

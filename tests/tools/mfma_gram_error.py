@@ -9,11 +9,11 @@ roofline: 2 E F = 7 GFLOP of float64 for the 200k-point tri-modal chunk is ~0.09
 measured -- the kernel is bound by bringing the neighbours' feature rows to the lanes, which a Gram tile needs as well
 (and it would compute all ~115 candidates per point instead of the ~37 inside the radius).  DESIGN.md section 5.
 
-    python tools/mfma_gram_error.py [n]  -> one JSON line (profiles/r02_mfma_gram_error.json)
+    python tests/tools/mfma_gram_error.py [n]  -> one JSON line (profiles/r02_mfma_gram_error.json)
 """
 import json, os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from autoinst_amd import synth
 from oracle import ncuts_ref
 

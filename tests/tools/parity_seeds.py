@@ -1,12 +1,12 @@
 """Device vs NumPy model of the device algorithm on several seeds / sizes (GPU box).
 
-    python tools/parity_seeds.py 15000 1 2 3 4 5 6
+    python tests/tools/parity_seeds.py 15000 1 2 3 4 5 6
 Prints one line per seed: groups, identical partition (and order) or the ARI.
 """
 import json, os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 from autoinst_amd import ncuts_api as api, synth
 from oracle import ncuts_ref
 import gpu_model

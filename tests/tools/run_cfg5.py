@@ -9,13 +9,13 @@ Lanczos with full re-orthogonalisation (`lanczos_fro`, still used for small grap
 within its 4000-step cap: 102 s, residual 5e-4 (profiles/r02_cfg5_lanczos_fro.json).  The reference itself only ever asks for k = 2 (normalized_cut.py:49), so parity
 is by properties: residuals, orthonormality, ascending eigenvalues (SciPy comparison at 30k rows: tests/test_gpu_fullsize.py).
 
-    python tools/run_cfg5.py [n] [extent] [k]  -> one JSON line
+    python tests/tools/run_cfg5.py [n] [extent] [k]  -> one JSON line
 """
 import json, os, sys, time
 import numpy as np
 import scipy.sparse as sp
 from scipy.sparse.csgraph import connected_components
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from autoinst_amd import ncuts_api as api, synth
 from oracle import ncuts_ref   # checker only: residuals are formed with SciPy's CSR product

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""BASELINE.json configs[0], [3] on one GPU (configs[1] is bench.py, configs[2] tools/run_cfg3.py, configs[4] tools/run_cfg5.py).
+"""BASELINE.json configs[0], [3] on one GPU (configs[1] is bench.py, configs[2] tools/run_cfg3.py, configs[4] tests/tools/run_cfg5.py).
 
     python tools/run_cfgs.py            # prints one JSON line per config
 """
@@ -48,7 +48,7 @@ def main():
     _, dt = timed(cfg4_dev)
     print(json.dumps({"config": "cfg4 affinity only, features resident in HBM", "ms": 1e3 * dt}), flush=True)
     del tp, tt, td, ch
-    # cfg5 (1M points, k = 64) has its own driver: tools/run_cfg5.py
+    # cfg5 (1M points, k = 64) has its own driver: tests/tools/run_cfg5.py
 
 
 if __name__ == "__main__":
