@@ -356,7 +356,9 @@ __device__ __forceinline__ double aw_weight(double dist, double t2, double g2, b
 }
 
 // Lanes over dimensions: 8 lanes share one entry and each owns two dimensions of the slab, so a 16-lane row group reads
-// two staged rows as two contiguous 128-byte segments (one ds_read_b128 per lane, conflict-free), the row's own values sit
+// two staged rows as two contiguous 128-byte segments (one ds_read_b128 per lane; the two segments of a 16-lane clock group
+// share their 32 banks when the two staged positions have the same parity: 2-way conflicts half of the time, 35 % of the LDS
+// cycles by SQ_LDS_BANK_CONFLICT, profiles/r02_pmc_affinity.txt), the row's own values sit
 // in two registers, and the per-entry partial sums stay in registers across the slabs (ACC accumulators = 2 * ACC entry
 // slots per row per round; a slot without an entry points at the row itself and adds zeros).  (Round 2's first tiled
 // form gave every lane its own entries and walked a slab's 16 dimensions sequentially: 64 lanes then read 64 different
