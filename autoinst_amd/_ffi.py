@@ -62,6 +62,17 @@ def load():
         raise AutoinstHipError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C autoinst_amd/csrc`).  autoinst_amd has no CPU fallback.")
+    # torch ships its own HIP runtime; a process that uses both must let torch initialise its runtime FIRST (the library then
+    # resolves to the runtime already loaded).  The other order leaves torch without devices ("No HIP GPUs are available").
+    # So: if torch is already imported, make it initialise now; a program that imports torch later must do so before this call.
+    import sys
+    if "torch" in sys.modules:
+        try:
+            t = sys.modules["torch"]
+            if t.cuda.is_available():
+                t.cuda.init()
+        except Exception:  # noqa: BLE001 -- torch without a device: the library reports its own error below
+            pass
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # e.g. the ROCm runtime is absent

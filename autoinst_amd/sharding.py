@@ -6,6 +6,10 @@ The reference runs ``for sequence in tqdm(range(#chunks)): ncuts_chunk(...)`` se
 longest-processing-time assignment by chunk size, and one gather of the int32 label arrays to
 rank 0 at the end (a few hundred KB per chunk: RCCL over xGMI with the ``nccl`` backend, ``gloo``
 in CPU tests).  ``merge_chunks_unite_instances2`` stays serial on rank 0, as in the reference.
+
+Inside one rank `run_chunks` is that loop for one GPU: a few host threads (one `Context` each) take batches of
+chunks from one queue and push each batch through ONE batched call (`ncuts_labels_batch`: the chunks are the root
+segments of one frontier) -- the arrangement `bench.py` measures.
 """
 from __future__ import annotations
 
@@ -79,3 +83,83 @@ def gather_labels(local: dict, device=None, force: bool = False):
             merged[k] = a[off: off + ln].copy()
             off += ln
     return merged
+
+
+
+def run_chunks(chunks, *, threads: int = 4, batch: int = 6, device: int | None = None, alpha=None, theta=None, gamma=None,
+               T=None, split_lim=None, contexts=None):
+    """The chunk loop of ``run_pipeline.py:160-179`` for the chunks of ONE rank / GPU.
+
+    ``chunks``: sequence of ``(points, tarl)`` or ``(points, tarl, dino)`` (host arrays or device tensors; ``tarl`` / ``dino``
+    may be ``None``).  Returns the list of int32 label arrays (``label[i]`` = group of point ``i``, groups numbered in the
+    reference's emission order), chunk by chunk -- what `ncuts_api.ncuts_labels` gives for each chunk alone.
+
+    Chunks are batched largest first (``batch`` per call, so that the chunks of a call take similar numbers of levels);
+    ``threads`` host threads with one `Context` each (or the given ``contexts``) take batches from one queue, and the C calls
+    release the GIL, so ``threads`` batched calls are in flight on the device together.  A failure in any batch is raised
+    after the other threads have finished their current batch.
+    """
+    import queue
+    import threading
+
+    from . import ncuts_api as api
+    from .config import CONFIG, SPLIT_LIM
+
+    cfg = {"alpha": CONFIG["alpha"] if alpha is None else alpha, "theta": CONFIG["theta"] if theta is None else theta,
+           "gamma": CONFIG["gamma"] if gamma is None else gamma}
+    T = CONFIG["T"] if T is None else T
+    split_lim = SPLIT_LIM if split_lim is None else split_lim
+    n_chunks = len(chunks)
+    if n_chunks == 0:
+        return []
+    if threads <= 0 or batch <= 0:
+        raise ValueError("threads and batch must be positive")
+    sizes = [int(c[0].shape[0]) for c in chunks]
+    order = sorted(range(n_chunks), key=lambda i: (-chunk_cost(sizes[i]), i))
+    batches = [order[j:j + batch] for j in range(0, n_chunks, batch)]
+    threads = min(threads, len(batches))
+    own = contexts is None   # contexts made here are closed here; pass `contexts` to keep their workspaces between calls
+    ctxs = list(contexts) if contexts is not None else [api.Context(device) for _ in range(threads)]
+    if len(ctxs) < threads:
+        raise ValueError("fewer contexts than threads")
+    work = queue.Queue()
+    for b in batches:
+        work.put(b)
+    out = [None] * n_chunks
+    errors = []
+
+    def worker(w):
+        while not errors:
+            try:
+                ids = work.get_nowait()
+            except queue.Empty:
+                return
+            graphs = []
+            try:
+                for i in ids:
+                    c = chunks[i]
+                    graphs.append(api.build_affinity(c[0], c[1] if len(c) > 1 else None, c[2] if len(c) > 2 else None, ctx=ctxs[w], **cfg))
+                if len(graphs) == 1:
+                    lab, _, _ = api.ncuts_labels(graphs[0], sizes[ids[0]], T, split_lim)
+                    labs = [lab]
+                else:
+                    labs, _, _ = api.ncuts_labels_batch(graphs, [sizes[i] for i in ids], T, split_lim)
+                for i, lab in zip(ids, labs):
+                    out[i] = lab
+            except BaseException as e:  # noqa: BLE001 -- re-raised in the caller's thread
+                errors.append(e)
+            finally:
+                for g in graphs:
+                    g.free()
+
+    ts = [threading.Thread(target=worker, args=(w,)) for w in range(threads)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if own:
+        for c in ctxs:
+            c.close()
+    if errors:
+        raise errors[0]
+    return out

@@ -717,3 +717,49 @@ def test_thousands_of_isolated_points_and_small_components(api):
     assert small.size >= 2300 and len(groups) >= small.size + 1
     exp = gpu_model.normalized_cut_model(A, n, np.arange(n), T=0.075)
     assert len(exp) == len(groups) and ncuts_ref.partitions_equal(lab, ncuts_ref.groups_to_labels(exp, n))
+
+
+def test_run_chunks_equals_one_chunk_at_a_time(api):
+    """`sharding.run_chunks` (host threads taking batches from one queue, one batched call per batch -- the chunk loop of
+    run_pipeline.py:160-179 for one GPU) returns, chunk by chunk, the labels of a plain sequential call; chunks of very
+    different sizes, one too small to be split."""
+    from autoinst_amd import sharding, synth
+    specs = [(9000, 31), (3000, 32), (15000, 33), (150, 34), (6000, 35), (12000, 36), (4000, 37), (7000, 38), (2500, 39)]
+    chunks = [synth.synthetic_chunk(n, seed, tarl=True) for n, seed in specs]
+    args = [(c["points"], c["tarl"]) for c in chunks]
+    got = sharding.run_chunks(args, threads=3, batch=2, alpha=1.0, theta=0.5, gamma=0.0, T=0.03)
+    assert len(got) == len(chunks)
+    for c, lab in zip(chunks, got):
+        g = api.build_affinity(c["points"], c["tarl"], alpha=1.0, theta=0.5, gamma=0.0)
+        ref, _, _ = api.ncuts_labels(g, g.n, 0.03)
+        g.free()
+        assert np.array_equal(lab, ref)
+    # one thread, one chunk per call: the same again
+    again = sharding.run_chunks(args[:3], threads=1, batch=1, alpha=1.0, theta=0.5, gamma=0.0, T=0.03)
+    assert all(np.array_equal(a, b) for a, b in zip(again, got[:3]))
+
+
+def test_device_tensors_in_a_torch_first_process(tmp_path):
+    """Inputs already resident in HBM (torch tensors -> raw device pointers, AI_MEM_DEVICE) give the labels of the host-array
+    path.  torch ships its own HIP runtime and must initialise first (autoinst_amd/_ffi.py does that when torch is already
+    imported), so this runs in a process of its own that imports torch before the package."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = f"""
+import sys, numpy as np, torch
+sys.path.insert(0, {ROOT!r})
+from autoinst_amd import ncuts_api as api, sharding, synth
+ch = [synth.synthetic_chunk(n, s, tarl=True) for n, s in ((8000, 41), (5000, 42), (11000, 43))]
+host = [(c["points"], c["tarl"]) for c in ch]
+dev = [(torch.from_numpy(p).cuda(), torch.from_numpy(f).cuda()) for p, f in host]
+a = sharding.run_chunks(host, threads=2, batch=2, alpha=1.0, theta=0.5, gamma=0.0, T=0.03)
+b = sharding.run_chunks(dev, threads=2, batch=2, alpha=1.0, theta=0.5, gamma=0.0, T=0.03)
+assert all(np.array_equal(x, y) for x, y in zip(a, b))
+g = api.build_affinity(dev[0][0], dev[0][1], alpha=1.0, theta=0.5, gamma=0.0)
+lab, ng, _ = api.ncuts_labels(g, g.n, 0.03); g.free()
+assert np.array_equal(lab, a[0]) and ng > 1
+print("ok", ng)
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().startswith("ok"), r.stdout + r.stderr

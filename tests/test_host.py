@@ -5,6 +5,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 from conftest import ROOT
 from autoinst_amd import sharding, synth
@@ -75,3 +76,12 @@ def test_gather_labels_world_size_2_gloo(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "GATHER_OK" in outs[0]
+
+
+def test_run_chunks_argument_checks():
+    """`sharding.run_chunks` without work does not touch the GPU; bad thread / batch counts raise."""
+    assert sharding.run_chunks([]) == []
+    with pytest.raises(ValueError):
+        sharding.run_chunks([(np.zeros((3, 3)), None)], threads=0)
+    with pytest.raises(ValueError):
+        sharding.run_chunks([(np.zeros((3, 3)), None)], batch=0)

@@ -13,7 +13,6 @@ push `--batch` chunks per batched call, label arrays are gathered to rank 0 (RCC
 one JSON line.
 """
 import argparse, json, os, sys, time
-from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -31,33 +30,12 @@ def run_map(sizes, world, rank, local_rank, in_flight=4, dist=None, dev=None, ba
     from autoinst_amd import ncuts_api as api, sharding, synth
     mine = sharding.lpt_assign(sizes, world)[rank]
     ctxs = [api.Context(local_rank) for _ in range(in_flight)]
-    data = {i: synth.synthetic_chunk(sizes[i], seed=1000 + i, tarl=True) for i in mine}
-
-    def work(slot, ids):
-        """One batched call: the chunks are root segments of one frontier (ai_ncut_batch)."""
-        graphs = [api.build_affinity(data[i]["points"], data[i]["tarl"], alpha=1.0, theta=0.5, gamma=0.0, ctx=ctxs[slot]) for i in ids]
-        try:
-            labs, ngs, st = api.ncuts_labels_batch(graphs, None, 0.03)
-        finally:
-            for g in graphs:
-                g.free()
-        return list(zip(ids, labs))
-
-    # largest first, dealt round-robin to the host threads; a thread pushes `batch` chunks per call
-    order = sorted(mine, key=lambda i: -sizes[i])
+    data = [synth.synthetic_chunk(sizes[i], seed=1000 + i, tarl=True) for i in mine]
     t0 = time.perf_counter()
-    out = {}
-    with ThreadPoolExecutor(max_workers=in_flight) as pool:
-        lanes = [order[k::in_flight] for k in range(in_flight)]
-        def lane(k):
-            res = []
-            for j in range(0, len(lanes[k]), batch):
-                res += work(k, lanes[k][j:j + batch])
-            return res
-        for res in pool.map(lane, range(in_flight)):
-            for i, lab in res:
-                out[i] = lab
-    merged = sharding.gather_labels(out, device=dev)
+    # the rank's chunk loop: host threads take batches (largest chunks first) from one queue, one batched call per batch
+    labs = sharding.run_chunks([(d["points"], d["tarl"]) for d in data], threads=in_flight, batch=batch, contexts=ctxs,
+                               alpha=1.0, theta=0.5, gamma=0.0, T=0.03)
+    merged = sharding.gather_labels(dict(zip(mine, labs)), device=dev)
     return merged, time.perf_counter() - t0
 
 
