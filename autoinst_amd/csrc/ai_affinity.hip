@@ -131,12 +131,17 @@ __global__ __launch_bounds__(AI_BLOCK) void k_neighbours(const double* __restric
                                                          const int32_t* __restrict__ cstart, const int32_t* __restrict__ cend,
                                                          int64_t n, Grid g, double radius, int32_t* __restrict__ cnt,
                                                          const int32_t* __restrict__ rowptr, int32_t* __restrict__ col,
-                                                         double* __restrict__ dist) {
+                                                         double* __restrict__ dist, int32_t* __restrict__ stash_col,
+                                                         double* __restrict__ stash_dist, int stash_cap,
+                                                         const int32_t* __restrict__ cnt_in) {
+  // FILL = false with a stash: the counting pass also keeps the first stash_cap hits of every row (ids + distances, row p at
+  // p * stash_cap), so that filling the CSR is a copy (k_nb_unstash) instead of a second walk; FILL = true with cnt_in: only
+  // the rows with more than stash_cap neighbours are walked again.
   const int64_t gid = (int64_t)blockIdx.x * AI_BLOCK + threadIdx.x;
   const int64_t p = gid / AI_NB_LANES;
   const int l = (int)(gid % AI_NB_LANES);
   const int sub = (threadIdx.x & 63) / AI_NB_LANES;  // which group of the wave
-  const bool live = p < n;
+  const bool live = p < n && !(FILL && cnt_in != nullptr && cnt_in[p < n ? p : 0] <= stash_cap);
   // every lane of the wave runs the same loops (ballots need the whole wave); a dead group simply finds nothing
   const int64_t pp = live ? p : n - 1;
   const double x = X[pp], y = Y[pp], z = Z[pp];
@@ -183,6 +188,13 @@ __global__ __launch_bounds__(AI_BLOCK) void k_neighbours(const double* __restric
             col[base + k + before] = q;
             dist[base + k + before] = d;
           }
+          if (!FILL && hit && stash_col != nullptr) {
+            const int at = k + __popc(gbits & ((1u << l) - 1u));
+            if (at < stash_cap) {
+              stash_col[p * stash_cap + at] = q;
+              stash_dist[p * stash_cap + at] = d;
+            }
+          }
           k += __popc(gbits);
         }
       }
@@ -197,6 +209,31 @@ __global__ __launch_bounds__(AI_BLOCK) void k_count_total(const int32_t* __restr
   for (int64_t i = (int64_t)blockIdx.x * AI_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * AI_BLOCK) a += (unsigned long long)cnt[i];
   for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
   if ((threadIdx.x & 63) == 0 && a) atomicAdd(total, a);
+}
+
+// the stashed hits of the counting pass into their CSR rows (rows with more than `cap` neighbours are left to a second walk)
+__global__ __launch_bounds__(AI_BLOCK) void k_nb_unstash(const int32_t* __restrict__ cnt, const int32_t* __restrict__ rowptr,
+                                                         const int32_t* __restrict__ stash_col, const double* __restrict__ stash_dist,
+                                                         int cap, int64_t n, int32_t* __restrict__ col, double* __restrict__ dist) {
+  const int64_t gid = (int64_t)blockIdx.x * AI_BLOCK + threadIdx.x;
+  const int64_t p = gid / AI_NB_LANES;
+  const int l = (int)(gid % AI_NB_LANES);
+  if (p >= n) return;
+  const int c = cnt[p];
+  if (c > cap) return;
+  const int32_t base = rowptr[p];
+  for (int k = l; k < c; k += AI_NB_LANES) {
+    col[base + k] = stash_col[p * cap + k];
+    dist[base + k] = stash_dist[p * cap + k];
+  }
+}
+
+// rows with more than `cap` neighbours (they need the second walk)
+__global__ __launch_bounds__(AI_BLOCK) void k_count_over(const int32_t* __restrict__ cnt, int64_t n, int cap, unsigned long long* __restrict__ over) {
+  unsigned long long a = 0;
+  for (int64_t i = (int64_t)blockIdx.x * AI_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * AI_BLOCK) a += (cnt[i] > cap) ? 1ull : 0ull;
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+  if ((threadIdx.x & 63) == 0 && a) atomicAdd(over, a);
 }
 
 // all-zero feature row = "no TARL feature for this point" (ncuts_utils.py:143)
@@ -759,20 +796,30 @@ extern "C" int ai_affinity_build_sam(ai_ctx* ctx, const double* xyz, int64_t n, 
   hipLaunchKernelGGL(k_cell_ranges, dim3(gb), dim3(AI_BLOCK), 0, st, cellid.p, n, cstart.p, cend.p);
   AI_HIPF(hipGetLastError());
   const unsigned gnb = (unsigned)((n * AI_NB_LANES + AI_BLOCK - 1) / AI_BLOCK);
+  // the counting walk keeps its hits (up to AI_NB_STASH per row), so that filling the CSR is a copy
+  constexpr int AI_NB_STASH = 128;
+  DevBuf<int32_t> stash_col;
+  DevBuf<double> stash_dist;
+  AI_TRYF(stash_col.alloc((size_t)n * AI_NB_STASH));
+  AI_TRYF(stash_dist.alloc((size_t)n * AI_NB_STASH));
   hipLaunchKernelGGL(k_neighbours<false>, dim3(gnb), dim3(AI_BLOCK), 0, st, X.p, Y.p, Z.p, cellid.p, cstart.p, cend.p, n, g,
-                     radius, cnt.p, (const int32_t*)nullptr, (int32_t*)nullptr, (double*)nullptr);
+                     radius, cnt.p, (const int32_t*)nullptr, (int32_t*)nullptr, (double*)nullptr, stash_col.p, stash_dist.p, AI_NB_STASH,
+                     (const int32_t*)nullptr);
   AI_HIPF(hipGetLastError());
   DevBuf<unsigned long long> total;
-  AI_TRYF(total.alloc(1));
-  AI_HIPF(hipMemsetAsync(total.p, 0, sizeof(unsigned long long), st));
+  AI_TRYF(total.alloc(2));
+  AI_HIPF(hipMemsetAsync(total.p, 0, 2 * sizeof(unsigned long long), st));
   hipLaunchKernelGGL(k_count_total, dim3(256), dim3(AI_BLOCK), 0, st, (const int32_t*)cnt.p, n, total.p);
+  AI_HIPF(hipGetLastError());
+  hipLaunchKernelGGL(k_count_over, dim3(256), dim3(AI_BLOCK), 0, st, (const int32_t*)cnt.p, n, AI_NB_STASH, total.p + 1);
   AI_HIPF(hipGetLastError());
   AI_TRYF(ai_exclusive_scan_i32(st, cnt.p, A->rowptr, n, scantmp.p));
   int32_t nnz32 = 0;
-  unsigned long long nnz64 = 0;
+  unsigned long long tot2[2] = {0, 0};
   AI_HIPF(hipMemcpyAsync(&nnz32, A->rowptr + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-  AI_HIPF(hipMemcpyAsync(&nnz64, total.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  AI_HIPF(hipMemcpyAsync(tot2, total.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   AI_HIPF(hipStreamSynchronize(st));
+  const unsigned long long nnz64 = tot2[0], rows_over = tot2[1];
   if (nnz64 >= (1ull << 31)) {
     ai_set_error("ai_affinity_build: the radius graph has %llu entries; this build indexes entries with int32 (< 2^31)", nnz64);
     return fail(AI_ERR_BAD_ARG);
@@ -784,9 +831,15 @@ extern "C" int ai_affinity_build_sam(ai_ctx* ctx, const double* xyz, int64_t n, 
   A->nnz = nnz32;
   AI_HIPF(ctx->graphs.alloc((void**)&A->col, (size_t)A->nnz * sizeof(int32_t)));
   AI_HIPF(ctx->graphs.alloc((void**)&A->val, (size_t)A->nnz * sizeof(double)));
-  hipLaunchKernelGGL(k_neighbours<true>, dim3(gnb), dim3(AI_BLOCK), 0, st, X.p, Y.p, Z.p, cellid.p, cstart.p, cend.p, n, g,
-                     radius, (int32_t*)nullptr, (const int32_t*)A->rowptr, A->col, A->val);
+  hipLaunchKernelGGL(k_nb_unstash, dim3(gnb), dim3(AI_BLOCK), 0, st, (const int32_t*)cnt.p, (const int32_t*)A->rowptr, (const int32_t*)stash_col.p,
+                     (const double*)stash_dist.p, AI_NB_STASH, n, A->col, A->val);
   AI_HIPF(hipGetLastError());
+  if (rows_over > 0) {  // dense clouds: the rows that did not fit the stash are walked a second time
+    hipLaunchKernelGGL(k_neighbours<true>, dim3(gnb), dim3(AI_BLOCK), 0, st, X.p, Y.p, Z.p, cellid.p, cstart.p, cend.p, n, g,
+                       radius, (int32_t*)nullptr, (const int32_t*)A->rowptr, A->col, A->val, (int32_t*)nullptr, (double*)nullptr,
+                       AI_NB_STASH, (const int32_t*)cnt.p);
+    AI_HIPF(hipGetLastError());
+  }
   if (d_tarl) {
     AI_TRYF(notarl.alloc(n));
     const unsigned gz = (unsigned)((n * 16 + AI_BLOCK - 1) / AI_BLOCK);

@@ -12,7 +12,7 @@ import csv, glob
 f = glob.glob("/tmp/pa/**/*kernel_stats.csv", recursive=True)[0]
 for r in csv.DictReader(open(f)):
     n = r["Name"].replace("(anonymous namespace)::", "").split("(")[0]
-    if any(k in n for k in ("weights", "neighbours", "zero_rows")):
+    if any(k in n for k in ("weights", "neighbours", "zero_rows", "unstash", "count_")):
         print(f"   {n:45s} calls {r['Calls']:>4s} avg_us {float(r['AverageNs'])/1e3:9.1f} min {float(r['MinNs'])/1e3:9.1f} max {float(r['MaxNs'])/1e3:9.1f}")
 PY
 done
