@@ -465,6 +465,19 @@ def main():
         labs1, ngs1, st, _ = one_batch(0, only_first=True)
     latency_ms = 1e3 * (time.perf_counter() - t1) / 3
     ng = ngs1[0]
+    # the same for every chunk of the step (the seed-0 chunk above is one of the most expensive of the 24): affinity build +
+    # normalized cut of one chunk alone, once each after a warm-up call
+    lat_all, steps_all = [], []
+    for i in range(M * B):
+        for rep in range(2):
+            p_, f_ = data[i]
+            t1 = time.perf_counter()
+            g_ = api.build_affinity(p_, f_, alpha=CFG["alpha"], theta=CFG["theta"], gamma=CFG["gamma"], ctx=ctxs[0])
+            _, _, st_i = api.ncuts_labels(g_, N_POINTS, CFG["T"])
+            g_.free()
+            dt_i = 1e3 * (time.perf_counter() - t1)
+        lat_all.append(dt_i)
+        steps_all.append(int(st_i["lanczos_steps"]))
     _, _, stp, _ = one_batch(0, profile="clock")
     _, _, stp_ev, _ = one_batch(0, profile="events")   # cross-check: HIP start/stop events on every dispatch
     # a plain device-to-device copy on the same box (quote the roofline against a measured stream number too):
@@ -520,7 +533,9 @@ def main():
             "host_inputs_note": "same loop, points + features in pinned host memory (159 MB per chunk), sent on a copy stream per host thread one batch ahead of its kernels"
                                 if elapsed_host else None,
             "hbm_in_use_gb": (total_b - free_b) / 1e9,   # inputs + K workspaces (arena, cached graph buffers) + torch
-            "single_chunk_latency_ms": latency_ms,
+            "single_chunk_latency_ms": latency_ms,   # the seed-0 chunk (per-chunk counters below are its)
+            "single_chunk_latency_ms_all": {"mean": sum(lat_all) / len(lat_all), "min": min(lat_all), "max": max(lat_all), "chunks": len(lat_all)},
+            "lanczos_steps_all": {"mean": sum(steps_all) / len(steps_all), "min": min(steps_all), "max": max(steps_all)},
             "batch_ncut_ms": stb["ms_total"],
             "eigensolve_ms": st["ms_eigen"],
             "ncut_ms": st["ms_total"],
