@@ -542,7 +542,7 @@ extern "C" int ai_bench_spmv(ai_ctx* ctx, const ai_csr* csr, int32_t reps, doubl
   if (block4) {
     AI_TRY(S.ensure_vec(AI_BP - 1));
     AI_TRY(S.Y4.ensure((size_t)csr->n * AI_BP));
-    AI_TRY(S.bl_pH.ensure((size_t)(S.lzf.n + 1) * 16));
+    AI_TRY(S.bl_pH.ensure((size_t)(S.lzf.n + 1) * AI_BP2));
     AI_TRY(S.bl_pG[0].ensure((size_t)(S.lzc.n + 1) * AI_BL_GVALS));
     hipLaunchKernelGGL(k_bl_init, dim3(S.lzc.n), dim3(AI_BLOCK), 0, st, S.lzc.d.p, S.cactive.p, S.orig, S.u1.p, S.vecb(0), S.bl_pG[0].p);
     AI_KERNEL_CHECK();
