@@ -8,10 +8,10 @@
 itself (one child process per GPU, started BEFORE this process imports torch or touches HIP; the
 parent only waits, relays rank 0's JSON line and returns non-zero if any rank failed).
 
-One "step" = one pass of the hot path over one batch of chunks per GPU: `--in-flight` (4) host
-threads, each with its own context / HIP streams, each pushing `--batch` (6) independent chunks
-through ONE batched call (the chunks are the root segments of one frontier and share every kernel
-launch): affinity build (TARL + spatial) from inputs already resident in HBM, recursive normalized
+One "step" = one pass of the hot path over one batch of chunks per GPU: `--batches` (4) batched calls of
+`--batch` (6) independent chunks each (the chunks of a call are the root segments of one frontier and share
+every kernel launch), taken from one queue by `--in-flight` (4) host threads with their own context / HIP
+streams: affinity build (TARL + spatial) from inputs already resident in HBM, recursive normalized
 cut, labels back on the host, and (N > 1) the gather of the label arrays to rank 0.  Workload =
 BASELINE.json configs[1]: a 200 000-point chunk, alpha = 1, theta = 0.5 (96-d features), T = 0.03;
 synthetic surface chunk.  Chunks are independent (reference `pipeline/run_pipeline.py:160-179`),
@@ -29,8 +29,11 @@ Rank 0 prints ONE JSON line.
 * `cpu_baseline` is the oracle (NumPy / SciPy restatement, scipy eigsh shift-invert as the reference):
   `value` = the MEASURED single-process run on the full 200k chunk (cached in `profiles/`, it takes hours),
   `pool` = a process pool on this host's cores over 20k-26k-point chunks, timed now.
-* `value_host_inputs` = the same loop with the inputs in pinned host memory (the library copies them on
-  the context's stream); `value` has them resident in HBM.
+* `value_host_inputs` = the same loop with the inputs in pinned host memory, sent on a copy stream per host thread
+  one batch ahead of its kernels; `value` has them resident in HBM.
+* `single_chunk_latency_ms` and the per-chunk counters are those of the seed-0 chunk alone; `single_chunk_latency_ms_all`
+  / `lanczos_steps_all` = mean / min / max over all chunks of the step, each alone.  `roofline.device_copy_gbps` = a
+  plain device-to-device copy on the same box.
 """
 from __future__ import annotations
 
