@@ -20,25 +20,8 @@ static thread_local ai_arena* g_arena = nullptr;
 ai_arena* ai_current_arena() { return g_arena; }
 void ai_set_current_arena(ai_arena* a) { g_arena = a; }
 
-void ai_arena::rewind() {
-  if (used > peak) peak = used;
-  used = 0;
-  cur = 0;
-  off = 0;
-  if (blocks.size() > 2) {
-    size_t want = peak + peak / 4 + ((size_t)1 << 20);
-    want = (want + 255) & ~(size_t)255;
-    for (auto& b : blocks) (void)hipFree(b.base);  // synchronises the device: nothing of the finished call is still running
-    blocks.clear();
-    Block nb;
-    nb.cap = want > min_block ? want : min_block;
-    if (hipMalloc((void**)&nb.base, nb.cap) == hipSuccess) blocks.push_back(nb);  // else: the next alloc() grows block by block again
-  }
-}
-
 void* ai_arena::alloc(size_t bytes) {
   bytes = (bytes + 255) & ~(size_t)255;
-  used += bytes;
   // first block, from the current one on, that still has room
   for (size_t b = cur; b < blocks.size(); ++b) {
     const size_t o = (b == cur) ? off : 0;
@@ -61,7 +44,6 @@ void ai_arena::release_all() {
   for (auto& b : blocks) (void)hipFree(b.base);
   blocks.clear();
   cur = off = 0;
-  used = 0;
 }
 hipError_t ai_graph_cache::alloc(void** out, size_t bytes) {
   std::lock_guard<std::mutex> lock(mu);

@@ -41,12 +41,8 @@ struct ai_arena {
   std::vector<Block> blocks;
   size_t cur = 0, off = 0;
   size_t min_block = (size_t)256 << 20;
-  size_t used = 0, peak = 0;  // bytes handed out in the running call; the largest such sum so far
   void* alloc(size_t bytes);  // nullptr on out-of-memory
-  // Between calls nothing is live.  A call whose requests do not fit the tail of a block moves on to the next one, so calls
-  // of varying shape make the list of blocks grow past what any one of them needs: once it has more than two blocks they
-  // are replaced by ONE block of the largest need seen so far (+ 25 %).
-  void rewind();
+  void rewind() { cur = 0, off = 0; }
   void release_all();
 };
 ai_arena* ai_current_arena();             // arena of the API call running on this thread (or nullptr)
