@@ -262,6 +262,7 @@ def main():
     ap.add_argument("--batches", type=int, default=0, help="batched calls per GPU per step (default: one per host thread)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-inputs", action="store_true", help="skip the pinned-host-input leg (value_host_inputs)")
+    ap.add_argument("--no-latency-all", action="store_true", help="skip the one-chunk-alone pass over all chunks of the step (profiled runs)")
     ap.add_argument("--dry", action="store_true", help="CPU-only rehearsal of the multi-rank plumbing (gloo), no compute")
     args = ap.parse_args()
 
@@ -471,7 +472,7 @@ def main():
     # the same for every chunk of the step (the seed-0 chunk above is one of the most expensive of the 24): affinity build +
     # normalized cut of one chunk alone, once each after a warm-up call
     lat_all, steps_all = [], []
-    for i in range(M * B):
+    for i in range(0 if args.no_latency_all else M * B):
         for rep in range(2):
             p_, f_ = data[i]
             t1 = time.perf_counter()
@@ -537,8 +538,8 @@ def main():
                                 if elapsed_host else None,
             "hbm_in_use_gb": (total_b - free_b) / 1e9,   # inputs + K workspaces (arena, cached graph buffers) + torch
             "single_chunk_latency_ms": latency_ms,   # the seed-0 chunk (per-chunk counters below are its)
-            "single_chunk_latency_ms_all": {"mean": sum(lat_all) / len(lat_all), "min": min(lat_all), "max": max(lat_all), "chunks": len(lat_all)},
-            "lanczos_steps_all": {"mean": sum(steps_all) / len(steps_all), "min": min(steps_all), "max": max(steps_all)},
+            "single_chunk_latency_ms_all": {"mean": sum(lat_all) / len(lat_all), "min": min(lat_all), "max": max(lat_all), "chunks": len(lat_all)} if lat_all else None,
+            "lanczos_steps_all": {"mean": sum(steps_all) / len(steps_all), "min": min(steps_all), "max": max(steps_all)} if steps_all else None,
             "batch_ncut_ms": stb["ms_total"],
             "eigensolve_ms": st["ms_eigen"],
             "ncut_ms": st["ms_total"],
