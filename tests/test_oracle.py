@@ -240,8 +240,8 @@ def test_the_oracle_disagrees_with_itself_only_under_reordering(base, tag):
     """The record behind the full-size tolerance (tests/test_gpu_goldens.py).  `_w*` = the same oracle run after
     other eigsh calls (another ARPACK start-vector state): the partition is the same up to a handful of points.
     `_p*` = the same points listed in another order: the <= 1 % remainders come out differently (SuperLU's
-    elimination order and round-off decide which component eigsh returns), ARI ~0.997-0.999 -- as far from the
-    oracle as the device is."""
+    elimination order and round-off decide which component eigsh returns), ARI 0.988-0.999 (0.988 on the 200k spatial
+    chunk, where the device is at 0.994 from the same oracle run) -- at least as far from the oracle as the device is."""
     import json
     a = np.load(os.path.join(GOLDEN, base + ".npz"))
     b = np.load(os.path.join(GOLDEN, f"{base}_{tag}.npz"))
@@ -252,7 +252,7 @@ def test_the_oracle_disagrees_with_itself_only_under_reordering(base, tag):
     if tag.startswith("w"):
         assert ari >= 0.999999 and abs(ma["groups"] - mb["groups"]) <= 1
     else:
-        assert 0.99 <= ari < 1.0 and abs(ma["groups"] - mb["groups"]) <= 3
+        assert 0.985 <= ari < 1.0 and abs(ma["groups"] - mb["groups"]) <= 3
 
 
 @pytest.mark.parametrize("name", ["c1_10k_spatial", "c1_10k_tarl"])
