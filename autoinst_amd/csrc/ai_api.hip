@@ -172,6 +172,13 @@ extern "C" int ai_ctx_destroy(ai_ctx* ctx) {
     if (ctx->chk_ev1[i]) (void)hipEventDestroy(ctx->chk_ev1[i]);
   }
   if (ctx->side) (void)hipStreamDestroy(ctx->side);
+  if (ctx->wave) {
+    (void)hipStreamSynchronize(ctx->wave);
+    (void)hipStreamDestroy(ctx->wave);
+  }
+  for (int i = 0; i < AI_FLOW_EVENTS; ++i)
+    if (ctx->fev[i]) (void)hipEventDestroy(ctx->fev[i]);
+  if (ctx->fpin) (void)hipHostFree(ctx->fpin);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->stage) (void)hipHostFree(ctx->stage);
   {

@@ -64,6 +64,8 @@ struct ArenaScope {
 #define AI_PINNED_INTS 4096
 #define AI_CHECK_DEPTH 16
 #define AI_STAGE_BYTES ((size_t)8 << 20)
+#define AI_FLOW_UPSLOTS 32                       // pinned upload ring of the asynchronous frontier (ai_flow.inc)
+#define AI_FLOW_EVENTS (AI_FLOW_UPSLOTS + 2)     // one event per upload slot + wave stage + main-stream mark
 // Device buffers of the graphs a context hands out (ai_csr): hipFree synchronises the whole device,
 // which with several host threads stalls every other thread's stream, so freed buffers are kept and
 // re-used by the next graph of similar size.
@@ -91,6 +93,9 @@ struct ai_ctx {
   hipEvent_t chk_ev[AI_CHECK_DEPTH];   // one event per in-flight check (recorded on `side`)
   hipEvent_t chk_ev1[AI_CHECK_DEPTH];  // main stream -> side stream hand-off of a check's inputs
   hipStream_t side;                    // convergence checks run here, beside the Lanczos steps
+  hipStream_t wave = nullptr;          // harvest waves of the asynchronous frontier (created on first use)
+  char* fpin = nullptr;                // its pinned host memory (uploads, check results, wave results)
+  hipEvent_t fev[AI_FLOW_EVENTS] = {};  // its events
   ai_arena arena;                      // call-scoped device workspace, kept between calls
   ai_graph_cache graphs;               // buffers of the graphs this context built
   char* stage;                         // AI_STAGE_BYTES of pinned host memory for packed small uploads / downloads

@@ -29,6 +29,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <deque>
+#include <map>
 #include <set>
 
 #include <hip/hip_ext.h>
@@ -42,10 +44,12 @@
 namespace {
 #include "ai_ncut_kernels.inc"
 #include "ai_ncut_solver.inc"
+#include "ai_flow_kernels.inc"
+#include "ai_flow.inc"
 }  // namespace
 
 // ----------------------------------------------------------------------------- recursion driver + C ABI
-static int ncut_impl(ai_ctx* ctx, const ai_csr* csr, int nchunks, const int64_t* off, const int64_t* n_orig, double T, double split_lim,
+static int ncut_lockstep(ai_ctx* ctx, const ai_csr* csr, int nchunks, const int64_t* off, const int64_t* n_orig, double T, double split_lim,
                      const ai_ncut_opts* opts, int32_t* const* labels_out, int32_t* n_groups, ai_ncut_stats* stats_out, double t0) {
   Solver S(ctx, csr);
   fill_opts(S, opts);
@@ -307,6 +311,14 @@ static int ncut_impl(ai_ctx* ctx, const ai_csr* csr, int nchunks, const int64_t*
   return AI_OK;
 }
 
+// AI_NCUT_LOCKSTEP=1 selects the level-synchronous driver (kept for A/B measurements); the default is the asynchronous frontier
+static int ncut_impl(ai_ctx* ctx, const ai_csr* csr, int nchunks, const int64_t* off, const int64_t* n_orig, double T, double split_lim,
+                     const ai_ncut_opts* opts, int32_t* const* labels_out, int32_t* n_groups, ai_ncut_stats* stats_out, double t0) {
+  static const int lockstep = getenv("AI_NCUT_LOCKSTEP") ? atoi(getenv("AI_NCUT_LOCKSTEP")) : 0;
+  if (lockstep) return ncut_lockstep(ctx, csr, nchunks, off, n_orig, T, split_lim, opts, labels_out, n_groups, stats_out, t0);
+  return ncut_flow(ctx, csr, nchunks, off, n_orig, T, split_lim, opts, labels_out, n_groups, stats_out, t0);
+}
+
 extern "C" int ai_ncut(ai_ctx* ctx, const ai_csr* csr, int64_t num_points_orig, double T, double split_lim, const ai_ncut_opts* opts,
                        int32_t* labels_out, int32_t* n_groups, ai_ncut_stats* stats_out) {
   if (!ctx || !csr || !labels_out || !n_groups || num_points_orig < 0) {
@@ -314,12 +326,10 @@ extern "C" int ai_ncut(ai_ctx* ctx, const ai_csr* csr, int64_t num_points_orig, 
     return AI_ERR_BAD_ARG;
   }
   AI_CHECK_GRAPH(csr, "ai_ncut");
-  AI_HIP(hipSetDevice(ctx->device));
-  const double t0 = now_ms();
-  ArenaScope arena_scope(&ctx->arena);  // declared before the solver: its buffers die first
-  const int64_t off[2] = {0, csr->n};
+  // one chunk = a batch of one: the recursion keeps its even depths in a call-owned copy of the graph
+  const ai_csr* graphs[1] = {csr};
   int32_t* lab[1] = {labels_out};
-  return ncut_impl(ctx, csr, 1, off, &num_points_orig, T, split_lim, opts, lab, n_groups, stats_out, t0);
+  return ai_ncut_batch(ctx, graphs, 1, &num_points_orig, T, split_lim, opts, lab, n_groups, stats_out);
 }
 
 extern "C" int ai_ncut_batch(ai_ctx* ctx, const ai_csr* const* graphs, int32_t count, const int64_t* num_points_orig, double T,
@@ -529,24 +539,7 @@ extern "C" int ai_bench_spmv(ai_ctx* ctx, const ai_csr* csr, int32_t reps, doubl
   AI_TRY(S.ensure_vec(0));
   hipLaunchKernelGGL(k_lz_init, dim3(S.lzc.n), dim3(AI_BLOCK), 0, st, S.lzc.d.p, S.cactive.p, S.orig, S.u1.p, S.vec(0), S.pB[0].p);
   AI_KERNEL_CHECK();
-  const bool block4 = getenv("AI_BLOCK_LANCZOS") && atoi(getenv("AI_BLOCK_LANCZOS")) != 0 && S.enc_ready;
-  auto launch = [&]() -> int {
-    if (!block4) return S.launch_spmv(0);
-    // the four-vector kernel of the block Lanczos path on the same whole-graph frontier
-    hipLaunchKernelGGL((k_bl_spmm<16, AI_ROW_ILP>), dim3(S.lzf.n), dim3(AI_BLOCK), 0, st, (const Task*)S.lzf.d.p, (const int32_t*)S.factive.p, S.lzf.n,
-                       (const TaskEnc*)S.enc.p, (const int32_t*)S.ucol.p, (const uint16_t*)S.lidx.p, S.rowptr, S.col, (const double*)S.wm.p,
-                       (const double*)S.sinv2.p, (const double*)S.vecb(0), S.Y4.p, S.bl_pH.p, (unsigned long long*)nullptr);
-    AI_KERNEL_CHECK();
-    return AI_OK;
-  };
-  if (block4) {
-    AI_TRY(S.ensure_vec(AI_BP - 1));
-    AI_TRY(S.Y4.ensure((size_t)csr->n * AI_BP));
-    AI_TRY(S.bl_pH.ensure((size_t)(S.lzf.n + 1) * AI_BP2));
-    AI_TRY(S.bl_pG[0].ensure((size_t)(S.lzc.n + 1) * AI_BL_GVALS));
-    hipLaunchKernelGGL(k_bl_init, dim3(S.lzc.n), dim3(AI_BLOCK), 0, st, S.lzc.d.p, S.cactive.p, S.orig, S.u1.p, S.vecb(0), S.bl_pG[0].p);
-    AI_KERNEL_CHECK();
-  }
+  auto launch = [&]() -> int { return S.launch_spmv(0); };
   for (int i = 0; i < 3; ++i) AI_TRY(launch());
   AI_HIP(hipEventRecord(ctx->ev[0], st));
   for (int i = 0; i < reps; ++i) AI_TRY(launch());

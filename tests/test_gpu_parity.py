@@ -272,7 +272,6 @@ def test_staged_gather_equals_plain_gather(api, monkeypatch, n, spread):
     pts = _dense_blobs(n, spread, n)
     g = api.build_affinity(pts, None, alpha=1.0, theta=0.0, gamma=0.0)
     assert g.nnz / g.n > (30 if spread > 1.5 else 128)
-    monkeypatch.setenv("AI_BLOCK_LANCZOS", "0")   # this test is about the single-vector SpMV's two gather forms
     monkeypatch.setenv("AI_SPMV_VARIANT", "0")
     l0, n0, s0 = api.ncuts_labels(g, n, 0.5)
     monkeypatch.setenv("AI_SPMV_VARIANT", "1")
@@ -282,7 +281,7 @@ def test_staged_gather_equals_plain_gather(api, monkeypatch, n, spread):
     assert n0 == n1 >= 2 and np.array_equal(l0, l1)
     # (lanczos_steps counts launches, including the few issued past convergence while a check was in flight)
     assert s0["lanczos_solves"] == s1["lanczos_solves"] > 0 and s0["unconverged"] == s1["unconverged"] == 0
-    assert abs(s0["max_resid"] - s1["max_resid"]) <= 1e-6 * s1["max_resid"]
+    assert abs(s0["max_resid"] - s1["max_resid"]) <= 0.5 * s1["max_resid"] and max(s0["max_resid"], s1["max_resid"]) <= 1e-9   # the two gather forms add in different orders: ~1e-16 in T, visible in a 1e-10 residual
     if spread < 1.5:   # (T = 0.5 on the sparse blob pair recurses into near-tie cuts: no model comparison there)
         exp = gpu_model.normalized_cut_model(A, n, np.arange(n), T=0.5)
         lab = np.empty(n, np.int64)
@@ -670,26 +669,6 @@ def test_apply_camera_on_an_uploaded_graph(api):
     got = g.to_scipy()
     assert np.array_equal(got.indices, want.indices) and (np.abs(got.data - want.data) / want.data).max() <= 1e-12
 
-
-def test_block_lanczos_path_gives_the_same_partitions(api, monkeypatch):
-    """The opt-in block Lanczos path (AI_BLOCK_LANCZOS=1: four vectors per step, band T, csrc/ai_block_lanczos.inc) converges
-    to the same Fiedler vectors: reference goldens for the eigenpair, and the default path's labels on a 200k chunk
-    (every Lanczos segment of every level has >= 1024 rows there, so the whole recursion takes the block path)."""
-    from autoinst_amd import synth
-    z, A, _, _ = load("g6_connected_tarl")
-    ch = synth.synthetic_chunk(200_000, seed=3, tarl=True)   # 1 % of the chunk = 2000 rows: every level qualifies
-    g = api.build_affinity(ch["points"], ch["tarl"], alpha=1.0, theta=0.5, gamma=0.0)
-    monkeypatch.setenv("AI_BLOCK_LANCZOS", "0")
-    l0, n0, s0 = api.ncuts_labels(g, g.n, 0.03)
-    monkeypatch.setenv("AI_BLOCK_LANCZOS", "1")
-    l1, n1, s1 = api.ncuts_labels(g, g.n, 0.03)
-    gg = api.DeviceGraph.from_scipy(A)
-    lam, ev, iters, resid = api.fiedler(gg)
-    g.free()
-    assert s1["unconverged"] == 0 and s1["lanczos_steps"] < 0.7 * s0["lanczos_steps"]   # block steps, about half as many
-    assert n0 == n1 and np.array_equal(l0, l1)
-    assert lam == pytest.approx(float(z["eigvals"][1]), rel=1e-8) and resid <= 1e-10
-    assert np.abs(np.abs(ev) - z["fiedler_abs"]).max() <= 1e-7
 
 
 def test_thousands_of_isolated_points_and_small_components(api):
