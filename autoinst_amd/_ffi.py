@@ -26,7 +26,7 @@ SYMBOLS = (
 
 
 class NcutOpts(C.Structure):
-    _fields_ = [("tol", C.c_double), ("max_iter", C.c_int32), ("check_every", C.c_int32), ("reserved", C.c_int32)]
+    _fields_ = [("tol", C.c_double), ("max_iter", C.c_int32), ("check_every", C.c_int32), ("reserved", C.c_int32), ("window_rows", C.c_int64)]
 
 
 class NcutStats(C.Structure):

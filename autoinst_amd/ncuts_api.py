@@ -236,10 +236,11 @@ def get_affinity_matrix(points, tarl=None, dino=None, *, alpha=CONFIG["alpha"], 
         g.free()
 
 
-def _opts(tol, max_iter, check_every, time_spmv=False):
-    """``time_spmv``: False, True / "events" (HIP events on every SpMV dispatch) or "clock" (device-clock stamps)."""
-    flag = 0 if not time_spmv else (2 if time_spmv == "clock" else 1)
-    return _ffi.NcutOpts(float(tol or 0.0), int(max_iter or 0), int(check_every or 0), flag)
+def _opts(tol, max_iter, check_every, time_spmv=False, window_rows=None):
+    """``time_spmv``: every SpMV launch stamps its span on the device clock (fills ``ms_spmv``).
+    ``window_rows``: points of the chunks of a batched call that iterate at one time (None: the library's default)."""
+    flag = 2 if time_spmv else 0
+    return _ffi.NcutOpts(float(tol or 0.0), int(max_iter or 0), int(check_every or 0), flag, int(window_rows or 0))
 
 
 def ncuts_labels(graph: DeviceGraph, num_points_orig: int, T: float, split_lim: float = SPLIT_LIM, *,
@@ -257,11 +258,12 @@ def ncuts_labels(graph: DeviceGraph, num_points_orig: int, T: float, split_lim: 
 
 
 def ncuts_labels_batch(graphs, num_points_orig=None, T=CONFIG["T"], split_lim=SPLIT_LIM, *, tol=None, max_iter=None,
-                       check_every=None, time_spmv=False):
+                       check_every=None, time_spmv=False, window_rows=None):
     """`ncuts_labels` for several independent chunks in ONE call (``ai_ncut_batch``).
 
-    The chunks share every kernel launch (they are the root segments of one frontier), which is
-    how a GPU is kept busy by a map's many chunks.  Returns ([labels_c], [n_groups_c], stats);
+    The connected segments of all chunks iterate in one pool and share every kernel launch, which is
+    how a GPU is kept busy by a map's many chunks; chunks beyond ``window_rows`` points wait inside the
+    call and are admitted as earlier ones finish.  Returns ([labels_c], [n_groups_c], stats);
     each chunk's result is what `ncuts_labels` gives for it alone.
     """
     global _last_stats
@@ -277,7 +279,7 @@ def ncuts_labels_batch(graphs, num_points_orig=None, T=CONFIG["T"], split_lim=SP
     no = (C.c_int64 * k)(*norig)
     ng = (C.c_int32 * k)()
     stats = _ffi.NcutStats()
-    o = _opts(tol, max_iter, check_every, time_spmv)
+    o = _opts(tol, max_iter, check_every, time_spmv, window_rows)
     _ffi.check(_ffi.load().ai_ncut_batch(ctx._h, gh, k, no, float(T), float(split_lim), C.byref(o), lp, ng, C.byref(stats)),
                "ai_ncut_batch")
     _last_stats = stats.as_dict()

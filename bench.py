@@ -8,10 +8,10 @@
 itself (one child process per GPU, started BEFORE this process imports torch or touches HIP; the
 parent only waits, relays rank 0's JSON line and returns non-zero if any rank failed).
 
-One "step" = one pass of the hot path over one batch of chunks per GPU: `--batches` (4) batched calls of
-`--batch` (6) independent chunks each (the chunks of a call are the root segments of one frontier and share
-every kernel launch), taken from one queue by `--in-flight` (4) host threads with their own context / HIP
-streams: affinity build (TARL + spatial) from inputs already resident in HBM, recursive normalized
+One "step" = one pass of the hot path over one batch of chunks per GPU: `--batches` (2) batched calls of
+`--batch` (12) independent chunks each (the connected segments of a call's chunks iterate in one pool, each at
+its own Lanczos step count, and share every kernel launch), taken from one queue by `--in-flight` (2) host
+threads with their own context / HIP streams: affinity build (TARL + spatial) from inputs already resident in HBM, recursive normalized
 cut, labels back on the host, and (N > 1) the gather of the label arrays to rank 0.  Workload =
 BASELINE.json configs[1]: a 200 000-point chunk, alpha = 1, theta = 0.5 (96-d features), T = 0.03;
 synthetic surface chunk.  Chunks are independent (reference `pipeline/run_pipeline.py:160-179`),
@@ -19,16 +19,16 @@ so the world's chunk list is dealt to the ranks by `sharding.lpt_assign` and the
 collective ("weak" scaling: the same number of chunks per rank per step).
 
 Rank 0 prints ONE JSON line.
-* `roofline` is for the dominant kernel (the fused Lanczos SpMV, `k_lz_spmv_q`): algorithmic bytes of its
+* `roofline` is for the dominant kernel (the fused Lanczos SpMV, `fk_spmv`): algorithmic bytes of its
   launches / their summed duration, measured live: every launch stamps its own span on the device clock (this
-  agrees with rocprofv3's per-kernel average; HIP start/stop events on every dispatch of the library's stream
-  are reported beside it for the solo regime -- they serialise the queue and read 10-30 % longer).  Two regimes are measured and both are reported: `frac_solo` (one batched call alone on
+  agrees with rocprofv3's per-kernel average).  Two regimes are measured and both are reported: `frac_solo` (one batched call alone on
   the device) and `frac_overlapped` (the `--in-flight` host threads in flight together, i.e. the regime
   `value` is quoted in); `frac` = the overlapped one.  `frac_aggregate` = all SpMV bytes of a step / the
   step's wall time.  The rocprofv3 summaries of both regimes are tracked under `profiles/`.
 * `cpu_baseline` is the oracle (NumPy / SciPy restatement, scipy eigsh shift-invert as the reference):
-  `value` = the MEASURED single-process run on the full 200k chunk (cached in `profiles/`, it takes hours),
-  `pool` = a process pool on this host's cores over 20k-26k-point chunks, timed now.
+  `value` = the MEASURED single-process run on the full 200k chunk (cached in `profiles/`, it takes hours; `cached_host`
+  says where it ran), `pool` = a process pool of min(host cores, 128) workers on THIS host over 20k-26k-point chunks,
+  timed now (`--cpu-50k` adds one single-process 50k-point run on this host, ~3 min).
 * `value_host_inputs` = the same loop with the inputs in pinned host memory, sent on a copy stream per host thread
   one batch ahead of its kernels; `value` has them resident in HBM.
 * `single_chunk_latency_ms` and the per-chunk counters are those of the seed-0 chunk alone; `single_chunk_latency_ms_all`
@@ -53,7 +53,7 @@ N_POINTS = 200_000
 CFG = dict(alpha=1.0, theta=0.5, gamma=0.0, T=0.03)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 CPU_200K_CACHE = os.path.join(ROOT, "profiles", "r02_cpu_oracle_200k.json")
-PMC_TRAFFIC = [os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"), os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")]
+PMC_TRAFFIC = [os.path.join(ROOT, "profiles", "r03_pmc_traffic.json"), os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")]
 
 
 def spmv_bytes(rows: int, nnz: int, launches: int) -> float:
@@ -107,7 +107,11 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(workers: int | None = None):
+def _cpu_one_worker(job):
+    return _cpu_pool_worker(job)
+
+
+def cpu_baseline(workers: int | None = None, with_50k: bool = False):
     """The oracle beside the GPU number.
 
     (i) `value`: the single-process oracle on the real 200k chunk, measured once in the build container by
@@ -118,7 +122,8 @@ def cpu_baseline(workers: int | None = None):
     import multiprocessing as mp
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     if workers is None:
-        workers = int(os.environ.get("AI_BENCH_CPU_WORKERS", min(avail, 16)))  # a 1-GPU box's CPU share is 16 cores
+        # the brief's target is quoted against a 128-core CPU run of the reference (run_pipeline.py:160-179 as a process pool)
+        workers = int(os.environ.get("AI_BENCH_CPU_WORKERS", min(avail, 128)))
     workers = max(1, workers)
     sizes = [int(x) for x in np.linspace(20_000, 26_000, workers)]
     jobs = [(n, i) for i, n in enumerate(sizes)]
@@ -127,6 +132,11 @@ def cpu_baseline(workers: int | None = None):
     with ctx.Pool(workers) as pool:
         res = pool.map(_cpu_pool_worker, jobs, chunksize=1)
     wall = time.perf_counter() - t0
+    same_box = None
+    if with_50k:   # one single-process run at 50k points on THIS host (the oracle grows faster than linearly in N)
+        with ctx.Pool(1) as pool:
+            n50, sec50, g50 = pool.map(_cpu_one_worker, [(50_000, 0)])[0]
+        same_box = {"n": n50, "seconds": sec50, "groups": g50, "chunks_per_sec": 1.0 / sec50, "cpu_model": _cpu_model()}
     pts = sum(r[0] for r in res)
     pool_info = {
         "cores": workers, "host_cores_available": avail, "cpu_model": _cpu_model(),
@@ -136,13 +146,15 @@ def cpu_baseline(workers: int | None = None):
         "per_chunk_seconds_min_max": [min(r[1] for r in res), max(r[1] for r in res)],
         "sample": f"{workers} workers x 1 chunk of {sizes[0]}-{sizes[-1]} points (seeds 0..{workers - 1}), oracle/ncuts_ref.ncuts, 1 BLAS thread each",
     }
-    out = {"unit": "chunks/sec", "kind": "port", "pool": pool_info}
+    out = {"unit": "chunks/sec", "kind": "port", "pool": pool_info, "single_process_50k_this_host": same_box}
     try:
         with open(CPU_200K_CACHE) as f:
             c = json.load(f)
         sec = float(c["affinity_seconds"]) + float(c["normalized_cut_seconds"])
         out.update({
             "value": 1.0 / sec, "cores": 1, "measured": True,
+            "cached_host": {"cpu_model": c["cpu_model"], "nproc": c["nproc"], "concurrent_jobs": c.get("concurrent_jobs", 1),
+                            "note": "the build container, not this host"},
             "sample": f"oracle/gen_fullsize.py on the full {c['n']}-point TARL+Spatial chunk (seed {c['seed']}), single process, "
                       f"measured {sec:.0f} s ({c['eigsh_calls']} eigsh calls, {c['groups']} groups) on {c['cpu_model']} "
                       f"({c['nproc']} cores, {c.get('concurrent_jobs', 1)} such jobs running side by side); cached in "
@@ -257,8 +269,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--in-flight", type=int, default=4, help="host threads (contexts) per GPU")
-    ap.add_argument("--batch", type=int, default=6, help="chunks per batched call (root segments of one frontier)")
+    ap.add_argument("--in-flight", type=int, default=2, help="host threads (contexts) per GPU")
+    ap.add_argument("--batch", type=int, default=12, help="chunks per batched call (their segments iterate in one pool)")
+    ap.add_argument("--cpu-50k", action="store_true", help="cpu_baseline: also one single-process 50k-point oracle run on this host (~3 min)")
     ap.add_argument("--batches", type=int, default=0, help="batched calls per GPU per step (default: one per host thread)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-inputs", action="store_true", help="skip the pinned-host-input leg (value_host_inputs)")
@@ -483,7 +496,6 @@ def main():
         lat_all.append(dt_i)
         steps_all.append(int(st_i["lanczos_steps"]))
     _, _, stp, _ = one_batch(0, profile="clock")
-    _, _, stp_ev, _ = one_batch(0, profile="events")   # cross-check: HIP start/stop events on every dispatch
     # a plain device-to-device copy on the same box (quote the roofline against a measured stream number too):
     # 1 GiB read + 1 GiB written per repeat, alone on the device
     src = torch.empty(1 << 27, dtype=torch.float64, device=dev).fill_(1.0)
@@ -530,7 +542,7 @@ def main():
             "rccl_ranks": dist.get_world_size() if world > 1 else 1,
             "backend": dist.get_backend() if world > 1 else "none",
             "config": {"workload": "configs[1]: single 200k-point surface chunk, TARL(96-d)+Spatial affinities, "
-                                   f"alpha=1 theta=0.5 T=0.03; per GPU per step {M} batched calls of {B} chunks (one frontier each) taken from a queue by {K} host threads",
+                                   f"alpha=1 theta=0.5 T=0.03; per GPU per step {M} batched calls of {B} chunks (one pool of iterating segments each) taken from a queue by {K} host threads",
                        "n_points": N_POINTS, "nnz": int(nnz), "chunks_per_step": world * M * B, "threads_per_gpu": K, "chunks_per_batch": B, "batches_per_step": M,
                        "parallelism": f"chunk-dp{world}"},
             "value_host_inputs": (world * M * B * host_steps / elapsed_host) if elapsed_host else None,
@@ -552,7 +564,7 @@ def main():
             "groups": int(ng),
             "unconverged": int(st["unconverged"]),
             "roofline": {
-                "kernel": "k_lz_spmv_q",
+                "kernel": "fk_spmv",
                 "bound": "hbm",
                 "achieved": ach_ov,
                 "peak": HBM_PEAK_GBPS,
@@ -569,15 +581,13 @@ def main():
                                "bytes_per_launch_avg": ov["bytes"] / max(ov["launches"], 1), "achieved_gbps": ach_ov,
                                "step_wall_ms_while_stamping": 1e3 * t_ov},
                 "solo": {"launches": launches, "avg_launch_us": 1e3 * stp["ms_spmv"] / max(launches, 1),
-                         "bytes_per_launch_avg": b / max(launches, 1), "achieved_gbps": ach_solo,
-                         "avg_launch_us_hip_events": 1e3 * stp_ev["ms_spmv"] / max(int(stp_ev["lanczos_steps"]), 1)},
-                "timer": "every SpMV launch stamps its own span (first block in .. last block out) on the device clock (wall_clock64); "
-                         "HIP start/stop events on every dispatch (avg_launch_us_hip_events) serialise the queue and read 10-30 % longer",
+                         "bytes_per_launch_avg": b / max(launches, 1), "achieved_gbps": ach_solo},
+                "timer": "every SpMV launch stamps its own span (first block in .. last block out) on the device clock (wall_clock64)",
                 "aggregate_gbps": ach_agg,
             },
         }
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only: the other ranks would sit in the final barrier
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(with_50k=args.cpu_50k)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -114,23 +114,24 @@ typedef struct {
   double tol;           /* Ritz residual |beta_m s_m| at which a Lanczos solve stops (default 1e-10) */
   int32_t max_iter;     /* Lanczos step cap per solve (default 4000; larger values are clamped to 4000: the convergence check keeps T_m in 64 KB of LDS) */
   int32_t check_every;  /* steps between convergence checks on large segments (default 16) */
-  int32_t reserved;     /* profiling, fills ms_spmv (for bench.py): bit 0 = HIP start/stop events on every SpMV dispatch; bit 1 = every SpMV launch stamps its own span (first block in .. last block out) on the device clock, which does not perturb how launches of several streams overlap */
+  int32_t reserved;     /* profiling, fills ms_spmv (for bench.py): bit 0 or 1 = every SpMV launch stamps its own span (first block in .. last block out) on the device clock, which does not perturb how launches of several streams overlap */
+  int64_t window_rows;  /* ai_ncut_batch: rows (points) of the chunks that iterate at one time; further chunks of the call are admitted as earlier ones finish, so the Lanczos vector storage is sized for the window, not for the call (0 = 4 800 000; never less than the call's largest chunk) */
 } ai_ncut_opts;
 
 typedef struct {
-  int64_t levels;          /* frontier levels processed */
+  int64_t levels;          /* harvest waves run (asynchronous frontier) / frontier levels processed (level-synchronous driver) */
   int64_t lanczos_solves;  /* connected segments solved by Lanczos */
   int64_t null_solves;     /* disconnected segments, split into their connected components in one step */
-  int64_t lanczos_steps;   /* sum over levels of lock-step Lanczos steps (= fused SpMV launches) */
+  int64_t lanczos_steps;   /* Lanczos steps launched (= fused SpMV launches); every iterating segment of the call takes part in a step at its own step count */
   int64_t spmv_rows;       /* rows processed by the SpMV kernel, summed over launches (exact, counted on device) */
   int64_t spmv_nnz;        /* stored entries processed by the SpMV kernel, summed over launches */
   int64_t unconverged;     /* solves that hit max_iter before tol */
   int64_t n_groups;
   double ms_total;         /* host wall time of the call */
-  double ms_eigen;         /* device time in the Lanczos / Ritz phase (HIP events) */
+  double ms_eigen;         /* wall time during which Lanczos segments were iterating (host clock) */
   double ms_spmv;          /* device time in the fused SpMV kernel alone (only with reserved bit 0 or 1) */
-  double ms_sweep;         /* device time in min/max + bin + sweep */
-  double ms_rebuild;       /* device time in CC + partition + CSR rebuild */
+  double ms_sweep;         /* level-synchronous driver only: device time in min/max + bin + sweep */
+  double ms_rebuild;       /* level-synchronous driver only: device time in CC + partition + CSR rebuild */
   double max_resid;        /* largest accepted Ritz residual */
 } ai_ncut_stats;
 
@@ -151,9 +152,10 @@ int ai_ncut(ai_ctx* ctx, const ai_csr* csr, int64_t num_points_orig, double T, d
 
 /*
  * The same recursion over `count` independent chunks at once (run_pipeline.py:160-179 loops over
- * them one by one).  The chunks become the root segments of ONE frontier, so every kernel launch is
- * shared by all of them: a single chunk's launches are latency-bound on small frontiers, a batch
- * fills them.  Per chunk c: graphs[c], num_points_orig[c], labels_out[c] (graphs[c]->n ints, group
+ * them one by one).  The connected segments of all chunks iterate in ONE pool, each at its own Lanczos
+ * step count, so every kernel launch is shared by all of them: a single chunk's launches are
+ * latency-bound, a batch fills them.  Chunks beyond opts->window_rows wait inside the call and are
+ * admitted as earlier ones finish (a whole map can be one call).  Per chunk c: graphs[c], num_points_orig[c], labels_out[c] (graphs[c]->n ints, group
  * ids from 0 in that chunk's own emission order), n_groups[c].  Results are those of `count`
  * separate ai_ncut calls.  stats (may be NULL) describes the whole batch.
  */

@@ -215,6 +215,59 @@ def test_batched_chunks_equal_separate_calls(api):
     assert ngs2[2] == 1 and np.all(labs2[2] == 0) and np.array_equal(labs2[0], labs[0])
 
 
+@pytest.mark.gpu
+def test_admission_window_and_many_chunks_in_one_call(api):
+    """The asynchronous frontier admits the chunks of a call as far as `window_rows` allows and the rest as earlier chunks
+    finish; every chunk's labels are those of its own call, whatever the window (the sizes of T at which a segment may
+    freeze depend on its own step count only).  40 chunks of the real size range in ONE call (a whole map)."""
+    from autoinst_amd import synth
+    rng = np.random.default_rng(7)
+    sizes = [int(x) for x in np.exp(rng.uniform(np.log(3000), np.log(12000), 40))]
+    chunks = [synth.synthetic_chunk(n, 100 + i, tarl=True) for i, n in enumerate(sizes)]
+    graphs = [api.build_affinity(c["points"], c["tarl"], alpha=1.0, theta=0.5, gamma=0.0) for c in chunks]
+    single = [api.ncuts_labels(g, g.n, 0.03) for g in graphs[:6]]
+    labs_all, ngs_all, st_all = api.ncuts_labels_batch(graphs, None, 0.03)
+    labs_win, ngs_win, st_win = api.ncuts_labels_batch(graphs, None, 0.03, window_rows=30_000)   # 3 - 8 chunks at a time
+    labs_one, ngs_one, _ = api.ncuts_labels_batch(graphs, None, 0.03, window_rows=1)             # one chunk at a time
+    for g in graphs:
+        g.free()
+    assert st_all["unconverged"] == 0 and st_win["unconverged"] == 0
+    assert ngs_all == ngs_win == ngs_one
+    for a, b, c in zip(labs_all, labs_win, labs_one):
+        assert np.array_equal(a, b) and np.array_equal(a, c)
+    for (l1, n1, _), l2, n2 in zip(single, labs_all, ngs_all):
+        assert n1 == n2 and np.array_equal(l1, l2)
+    assert st_win["lanczos_steps"] > st_all["lanczos_steps"]   # the window really serialised the chunks
+
+
+@pytest.mark.gpu
+def test_level_synchronous_driver_gives_the_same_labels(tmp_path):
+    """AI_NCUT_LOCKSTEP=1 (the level-synchronous driver, kept for A/B measurements) and the asynchronous frontier give
+    identical labels: same solver arithmetic per segment, same sweep, same emission order."""
+    import subprocess, sys, os
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from autoinst_amd import ncuts_api as api, synth\n"
+        "out = []\n"
+        "for n, seed in ((20000, 3), (6000, 4)):\n"
+        "    ch = synth.synthetic_chunk(n, seed, tarl=True)\n"
+        "    g = api.build_affinity(ch['points'], ch['tarl'], alpha=1.0, theta=0.5, gamma=0.0)\n"
+        "    lab, ng, st = api.ncuts_labels(g, n, 0.03)\n"
+        "    out.append(lab)\n"
+        "np.savez(sys.argv[1], *out)\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ("0", "1"):
+        path = str(tmp_path / f"labels_{mode}.npz")
+        env = dict(os.environ, AI_NCUT_LOCKSTEP=mode)
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=300)
+        res[mode] = np.load(path)
+    for k in res["0"].files:
+        assert np.array_equal(res["0"][k], res["1"][k])
+
+
+
 def test_radius_boundary_and_duplicates(api):
     """`spatial_distance <= PROXIMITY_THRESHOLD` is inclusive (ncuts_utils.py:61); duplicates have weight 1."""
     eps = np.nextafter(1.0, 2.0)
