@@ -3,7 +3,9 @@
 #ifndef AI_FINE_ROWS
 #define AI_FINE_ROWS 32      // rows per block in the 16-lanes-per-row kernels (2 rows in flight per lane group; 16 / 128 measured slower, 64: 20.6 vs 17.4 us per launch on a whole 200k graph, 111 vs 121 chunks/s with the quad kernel)
 #endif
+#ifndef AI_COARSE_ROWS
 #define AI_COARSE_ROWS 512   // rows per block in the thread-per-row kernels (256 / 1024 measured within 2 %)
+#endif
 #define AI_ROW_ILP (AI_FINE_ROWS / (AI_BLOCK / AI_LPR))
 #define AI_SLAB_VECS 32      // Lanczos vectors per HBM slab
 #define AI_ROW_PF 4         // rounds of 16 entries per row loaded together in the 16-lanes-per-row kernels

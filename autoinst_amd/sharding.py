@@ -7,9 +7,9 @@ longest-processing-time assignment by chunk size, and one gather of the int32 la
 rank 0 at the end (a few hundred KB per chunk: RCCL over xGMI with the ``nccl`` backend, ``gloo``
 in CPU tests).  ``merge_chunks_unite_instances2`` stays serial on rank 0, as in the reference.
 
-Inside one rank `run_chunks` is that loop for one GPU: a few host threads (one `Context` each) take batches of
-chunks from one queue and push each batch through ONE batched call (`ncuts_labels_batch`: the chunks are the root
-segments of one frontier) -- the arrangement `bench.py` measures.
+Inside one rank `run_chunks` is that loop for one GPU: two host threads (one `Context` each) take batches of
+chunks from one queue and push each batch through ONE batched call (`ncuts_labels_batch`: the connected segments of the
+call's chunks iterate in one pool, each at its own step count) -- the arrangement `bench.py` measures.
 """
 from __future__ import annotations
 
@@ -86,7 +86,7 @@ def gather_labels(local: dict, device=None, force: bool = False):
 
 
 
-def run_chunks(chunks, *, threads: int = 4, batch: int = 6, device: int | None = None, alpha=None, theta=None, gamma=None,
+def run_chunks(chunks, *, threads: int = 2, batch: int = 12, device: int | None = None, alpha=None, theta=None, gamma=None,
                T=None, split_lim=None, contexts=None):
     """The chunk loop of ``run_pipeline.py:160-179`` for the chunks of ONE rank / GPU.
 
@@ -94,7 +94,7 @@ def run_chunks(chunks, *, threads: int = 4, batch: int = 6, device: int | None =
     may be ``None``).  Returns the list of int32 label arrays (``label[i]`` = group of point ``i``, groups numbered in the
     reference's emission order), chunk by chunk -- what `ncuts_api.ncuts_labels` gives for each chunk alone.
 
-    Chunks are batched largest first (``batch`` per call, so that the chunks of a call take similar numbers of levels);
+    Chunks are batched largest first (``batch`` per call);
     ``threads`` host threads with one `Context` each (or the given ``contexts``) take batches from one queue, and the C calls
     release the GIL, so ``threads`` batched calls are in flight on the device together.  A failure in any batch is raised
     after the other threads have finished their current batch.

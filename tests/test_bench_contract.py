@@ -5,8 +5,14 @@ import os
 from conftest import ROOT
 
 
+def _newest_bench_line():
+    import glob
+    return sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_200k_line.json")))[-1]
+
+
 def test_committed_bench_line_has_the_contract_fields():
-    with open(os.path.join(ROOT, "profiles", "r01_bench_200k_line.json")) as f:
+    """The newest `profiles/r*_bench_200k_line.json` (a `python bench.py` run on an MI355X box)."""
+    with open(_newest_bench_line()) as f:
         line = json.loads(f.read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -23,6 +29,10 @@ def test_committed_bench_line_has_the_contract_fields():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1
+    if "r01" not in _newest_bench_line() and "r02" not in _newest_bench_line():
+        # since round 3: the pool is min(host cores, 128) workers and says which host the cached full-size run came from
+        assert c["pool"]["cores"] == min(c["pool"]["host_cores_available"], 128) and "cpu_model" in c["cached_host"]
+        assert r["kernel"] == "fk_spmv" and r["traffic"] is None or r["traffic"] > 0
 
 
 def test_bench_launches_its_own_ranks_dry():

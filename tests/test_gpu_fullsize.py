@@ -123,6 +123,27 @@ def test_cfg3_small_map_chunk_parallel_driver(api):
         assert np.array_equal(lab, merged[i])
 
 
+def test_cfg3_full_map_through_run_chunks(api):
+    """BASELINE configs[2] at its own size, on one GPU: the synthetic map of tools/run_cfg3.py (64 chunks of 3k-30k points
+    + 8 of 200k points = 2.3 M points; the sample map itself is not available offline) through `sharding.run_chunks`, the
+    chunk loop of run_pipeline.py:160-179 for one rank.  Ten chunks across the size range equal plain one-chunk calls."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import run_cfg3
+    from autoinst_amd import synth
+    sizes = run_cfg3.chunk_sizes(False)
+    assert len(sizes) == 72 and sum(sizes) > 2_000_000
+    merged, seconds = run_cfg3.run_map(sizes, 1, 0, 0, in_flight=2, batch=12)
+    assert sorted(merged) == list(range(72)) and all(merged[i].shape[0] == sizes[i] for i in merged)
+    print("cfg3 full map:", len(sizes), "chunks,", sum(sizes), "points,", seconds, "s")
+    for i in (0, 7, 19, 26, 33, 48, 57, 63, 64, 71):
+        ch = synth.synthetic_chunk(sizes[i], seed=1000 + i, tarl=True)
+        g = api.build_affinity(ch["points"], ch["tarl"], alpha=1.0, theta=0.5, gamma=0.0)
+        lab, ng, _ = api.ncuts_labels(g, sizes[i], 0.03)
+        g.free()
+        assert np.array_equal(lab, merged[i]), i
+
+
 def _largest_component(api, n, seed):
     from autoinst_amd import synth
     pts, _ = synth.surface_chunk(n, seed=seed)

@@ -73,3 +73,31 @@ def test_nn1_reprojection_matches_oracle():
     got_r = points_api.nn1_reproject(np.zeros((fine.shape[0], 3)), fine, colors, major, max_radius=0.2)
     exp_r = points_ref.nn1_reproject(np.zeros((fine.shape[0], 3)), fine, colors, major, max_radius=0.2)
     assert np.array_equal(got_r, exp_r)
+
+
+@pytest.mark.gpu
+def test_tarl_file_golden_through_pooling_and_affinity():
+    """On-disk format -> hot path, on the device: tests/golden/formats/tarl/000042.bin (the bytes the reference's reader
+    `get_tarl_features`, kitti_odometry_dataset.py:251-281, was run on) is read with `formats.read_tarl_bin`, its 211 feature
+    rows are pooled onto major-voxel points with `tarl_pool` (chunk_generation.py:243-256) and the pooled features go into
+    `build_affinity` (ncuts_utils.py:135-149): pooling == oracle/points_ref to 1e-12, affinity == oracle/ncuts_ref to 1e-12,
+    same pattern."""
+    import os
+    from conftest import GOLDEN
+    from autoinst_amd import formats, ncuts_api as api, points_api
+    from oracle import ncuts_ref
+    d = os.path.join(GOLDEN, "formats")
+    feat = formats.read_tarl_bin(os.path.join(d, "tarl", "000042.bin"))
+    exp = np.load(os.path.join(d, "expected.npz"))["tarl_000042"]
+    assert feat.dtype == np.float32 and np.array_equal(feat, exp)      # what the reference's reader returned
+    rng = np.random.default_rng(42)
+    src = rng.uniform(0.0, 3.0, (feat.shape[0], 3))                    # the scan points the 211 feature rows belong to
+    major = np.concatenate([src[rng.integers(0, src.shape[0], 150)] + rng.normal(0, 0.05, (150, 3)), rng.uniform(0, 3, (60, 3))])
+    pooled = points_api.tarl_pool(major, src, feat)
+    ref = points_ref.tarl_pool(major, src, feat, 0.175)
+    assert np.array_equal(~pooled.any(1), ~ref.any(1)) and 0 < (~ref.any(1)).sum() < major.shape[0]
+    assert np.abs(pooled - ref).max() <= 1e-12
+    A = api.get_affinity_matrix(major, pooled, None, alpha=1.0, theta=0.5, gamma=0.0)
+    B = ncuts_ref.affinity_sparse(major, ref, None, alpha=1.0, theta=0.5, gamma=0.0)
+    assert np.array_equal(A.indptr, B.indptr) and np.array_equal(A.indices, B.indices)
+    assert (np.abs(A.data - B.data) / B.data).max() <= 1e-12

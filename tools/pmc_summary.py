@@ -27,7 +27,7 @@ for name, agg in (("FETCH_SIZE", F), ("WRITE_SIZE", W)):
     for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:10]:
         lines.append(f"{k[:44]:44s} {name:12s} {len(v):9d} {sum(v):14.1f} {sum(v)/len(v):12.2f} {max(v):12.2f}")
     lines.append("")
-spmv = [k for k in F if k.startswith("void k_lz_spmv") or k.startswith("k_lz_spmv")]
+spmv = [k for k in F if "fk_spmv" in k or "k_lz_spmv" in k]
 res = {}
 if spmv:
     k = max(spmv, key=lambda x: sum(F[x]))

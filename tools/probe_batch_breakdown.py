@@ -3,7 +3,7 @@ sys.path.insert(0, ".")
 import torch
 from autoinst_amd import ncuts_api as api, synth
 dev = torch.device("cuda", 0)
-K=6
+K=int(sys.argv[1]) if len(sys.argv) > 1 else 12
 data=[]
 for k in range(K):
     ch = synth.synthetic_chunk(200000, k, tarl=True)

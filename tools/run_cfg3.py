@@ -26,7 +26,7 @@ def chunk_sizes(small: bool):
     return [int(x) for x in np.exp(rng.uniform(np.log(3000), np.log(30000), 64))] + [200_000] * 8
 
 
-def run_map(sizes, world, rank, local_rank, in_flight=4, dist=None, dev=None, batch=6):
+def run_map(sizes, world, rank, local_rank, in_flight=2, dist=None, dev=None, batch=12):
     from autoinst_amd import ncuts_api as api, sharding, synth
     mine = sharding.lpt_assign(sizes, world)[rank]
     ctxs = [api.Context(local_rank) for _ in range(in_flight)]
@@ -42,8 +42,8 @@ def run_map(sizes, world, rank, local_rank, in_flight=4, dist=None, dev=None, ba
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--small", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=4, help="host threads (contexts) per GPU")
-    ap.add_argument("--batch", type=int, default=6, help="chunks per batched call")
+    ap.add_argument("--in-flight", type=int, default=2, help="host threads (contexts) per GPU")
+    ap.add_argument("--batch", type=int, default=12, help="chunks per batched call")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
