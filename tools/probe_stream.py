@@ -16,7 +16,7 @@ ctx = api.Context(0)
 graphs = [api.build_affinity(*data[k % len(data)], alpha=1.0, theta=0.5, gamma=0.0, ctx=ctx) for k in range(B)]
 for rep in range(reps + 1):
     t0 = time.perf_counter()
-    labs, ngs, st = api.ncuts_labels_batch(graphs, None, 0.03)
+    labs, ngs, st = api.ncuts_labels_batch(graphs, None, 0.03, window_rows=int(os.environ.get("AI_NCUT_WINDOW_ROWS", "0")) or None, time_spmv=bool(os.environ.get("AI_PROBE_CLOCK")))
     dt = time.perf_counter() - t0
     print(json.dumps({"ms": 1e3 * dt, "chunks_per_s_cut_only": B / dt, "window": os.environ.get("AI_NCUT_WINDOW_ROWS"),
-                      **{k: st[k] for k in ("ms_total", "ms_eigen", "levels", "lanczos_steps")}}), flush=True)
+                      **{k: st[k] for k in ("ms_total", "ms_eigen", "ms_spmv", "spmv_rows", "spmv_nnz", "levels", "lanczos_steps")}}), flush=True)
