@@ -779,7 +779,8 @@ extern "C" int ai_affinity_build_sam(ai_ctx* ctx, const double* xyz, int64_t n, 
     DevBuf<uint8_t> tmp;
     AI_TRYF(tmp.alloc(tmp_bytes));
     AI_HIPF(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, key.p, key2.p, idx.p, A->orig, (size_t)n, 0, 30, st));
-    AI_HIPF(hipStreamSynchronize(st));  // tmp is released at scope exit
+    // tmp comes from the call's arena (released when the call returns, after the final synchronisation): no wait here
+    if (!ai_current_arena()) AI_HIPF(hipStreamSynchronize(st));
   }
   AI_TRYF(X.alloc(n));
   AI_TRYF(Y.alloc(n));
