@@ -322,36 +322,34 @@ def main():
         for ch in gen.map(lambda c: synth.synthetic_chunk(N_POINTS, seed=c % (M * B), tarl=True), my_chunks):
             data.append((torch.from_numpy(ch["points"]).to(dev), torch.from_numpy(ch["tarl"]).to(dev)))
             if not args.no_host_inputs and world == 1:   # the host-input leg is an N = 1 measurement
-                host.append((torch.from_numpy(ch["points"]).pin_memory(), torch.from_numpy(ch["tarl"]).pin_memory()))
+                host.append((ch["points"], ch["tarl"]))
     torch.cuda.synchronize()
 
-    # host-input leg: a copy stream and two sets of device staging buffers per host thread (allocated once), so that the
-    # transfer of the next batch runs beside the current batch's kernels
-    copy_streams = [torch.cuda.Stream(device=dev) for _ in range(K)] if host else []
-    stage_bufs = [[[(torch.empty_like(p, device=dev), torch.empty_like(f, device=dev)) for p, f in host[:B]] for _ in range(2)]
-                  for _ in range(K)] if host else []
-    stage_turn = [0] * K
-
-    def upload_async(k, w):
-        slot = stage_turn[w]
-        stage_turn[w] ^= 1
-        bufs = stage_bufs[w][slot]
-        with torch.cuda.stream(copy_streams[w]):
-            for (dp, df), (p, f) in zip(bufs, host[k * B:(k + 1) * B]):
-                dp.copy_(p, non_blocking=True)
-                df.copy_(f, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(copy_streams[w])
-        return bufs, ev
+    # host-input leg: each batch's inputs lie in ONE pinned block (points of the B chunks, then their features).  One loader
+    # thread sends the batches in queue order, one copy each on its own stream, into a ring of K+1 device staging blocks and
+    # hands each staged batch to whichever host thread is free next, so the transfer of the following batch runs beside the
+    # kernels of the K batches in flight.  (tools/probe_h2d_interference.py: copies queued back to back on a stream cost the
+    # kernels beside them 27 %, one copy at a time 1-4 %.)
+    host_blocks, stage_blocks, views = [], [], None
+    if host:
+        np_, nf_ = host[0][0].size, host[0][1].size
+        for k in range(M):
+            blk = torch.empty(B * (np_ + nf_), dtype=torch.float64).pin_memory()
+            for b, (p, f) in enumerate(host[k * B:(k + 1) * B]):
+                blk[b * np_:(b + 1) * np_] = torch.from_numpy(p).reshape(-1)
+                blk[B * np_ + b * nf_:B * np_ + (b + 1) * nf_] = torch.from_numpy(f).reshape(-1)
+            host_blocks.append(blk)
+        shp_p, shp_f = host[0][0].shape, host[0][1].shape
+        host = True
+        stage_blocks = [torch.empty(B * (np_ + nf_), dtype=torch.float64, device=dev) for _ in range(K + 1)]
+        views = lambda d: [(d[b * np_:(b + 1) * np_].view(shp_p), d[B * np_ + b * nf_:B * np_ + (b + 1) * nf_].view(shp_f)) for b in range(B)]
 
     def one_batch(k, profile=False, only_first=False, from_host=False, w=None, staged=None):
         # batch k of the rank's M batches, run by host thread w on that thread's context
         ctx = ctxs[k % K if w is None else w]
         sl = slice(k * B, (k + 1) * B)
         if from_host:
-            tens, ev = staged if staged is not None else upload_async(k, k % K if w is None else w)
-            ev.synchronize()   # issued one batch ago when prefetched: normally already complete
-            mine = tens
+            mine = staged      # the loader thread has put this batch into a device staging block
         else:
             mine = data[sl]
         mine = mine[: 1 if only_first else B]
@@ -377,24 +375,35 @@ def main():
     results = {}               # (step, batch) -> result
     cv = threading.Condition()
 
-    def worker(w):
-        nxt = None                      # a job taken ahead of time (host-input leg: its upload is already under way)
+    free_blocks = queue.Queue()
+    for i in range(len(stage_blocks)):
+        free_blocks.put(i)
+    uploads = queue.Queue()    # host-input jobs on their way to `work`
+
+    def loader():
+        cs = torch.cuda.Stream(device=dev)
         while True:
-            job, staged = (nxt if nxt is not None else (work.get(), None))
-            nxt = None
+            job = uploads.get()
             if job is None:
                 return
-            step, k, kw = job
+            i = free_blocks.get()
+            with torch.cuda.stream(cs):
+                stage_blocks[i].copy_(host_blocks[job[1]], non_blocking=True)
+            cs.synchronize()
+            work.put(job + (i,))
+
+    def worker(w):
+        while True:
+            job = work.get()
+            if job is None:
+                return
+            step, k, kw = job[:3]
             try:
-                if kw.get("from_host"):
-                    if staged is None:
-                        staged = upload_async(k, w)
-                    try:                # look one job ahead and start its transfer before this batch's kernels
-                        j2 = work.get_nowait()
-                        nxt = (j2, upload_async(j2[1], w) if (j2 is not None and j2[2].get("from_host")) else None)
-                    except queue.Empty:
-                        pass
-                    r = one_batch(k, w=w, staged=staged, **kw)
+                if len(job) == 4:
+                    try:
+                        r = one_batch(k, w=w, staged=views(stage_blocks[job[3]]), **kw)
+                    finally:
+                        free_blocks.put(job[3])
                 else:
                     r = one_batch(k, w=w, **kw)
             except BaseException as e:  # surface the failure in the consuming thread
@@ -404,6 +413,8 @@ def main():
                 cv.notify_all()
 
     workers = [threading.Thread(target=worker, args=(w,), daemon=True) for w in range(K)]
+    if host:
+        workers.append(threading.Thread(target=loader, daemon=True))
     for t in workers:
         t.start()
 
@@ -413,7 +424,7 @@ def main():
         results as they complete and (N > 1) gathers that step's label arrays to rank 0.  Returns the last step's results."""
         for s_ in range(nsteps):
             for k in range(M):
-                work.put((s_, k, kw))
+                (uploads if kw.get("from_host") else work).put((s_, k, kw))
         last = None
         for s_ in range(nsteps):
             with cv:
@@ -459,7 +470,7 @@ def main():
     # ---- the same loop with the inputs in pinned host memory (the library copies them on the context's stream)
     host_steps, elapsed_host = 0, None
     if host:
-        host_steps = max(2, args.steps // 4)
+        host_steps = args.steps   # as many as the resident leg: the first batch of each thread has nothing to hide its transfer behind
         run_steps(1, from_host=True)
         elapsed_host, _ = timed(host_steps, from_host=True)
 
@@ -513,6 +524,7 @@ def main():
     barrier()
     for _ in range(K):
         work.put(None)
+    uploads.put(None)
     for t in workers:
         t.join()
 
@@ -546,7 +558,7 @@ def main():
                        "n_points": N_POINTS, "nnz": int(nnz), "chunks_per_step": world * M * B, "threads_per_gpu": K, "chunks_per_batch": B, "batches_per_step": M,
                        "parallelism": f"chunk-dp{world}"},
             "value_host_inputs": (world * M * B * host_steps / elapsed_host) if elapsed_host else None,
-            "host_inputs_note": "same loop, points + features in pinned host memory (159 MB per chunk), sent on a copy stream per host thread one batch ahead of its kernels"
+            "host_inputs_note": "same loop, each batch's points + features in one pinned host block (159 MB per chunk), sent by a loader thread with one copy per batch into a ring of three device staging blocks, one batch ahead of the kernels"
                                 if elapsed_host else None,
             "hbm_in_use_gb": (total_b - free_b) / 1e9,   # inputs + K workspaces (arena, cached graph buffers) + torch
             "single_chunk_latency_ms": latency_ms,   # the seed-0 chunk (per-chunk counters below are its)
