@@ -22,6 +22,7 @@ SYMBOLS = (
     "ai_sweep", "ai_lsym_apply", "ai_bench_spmv", "ai_eigs_smallest",
     "ai_radius_mean_pool", "ai_nn1_project", "ai_ncut_batch",
     "ai_label_pairs", "ai_merge_associate", "ai_unique_points", "ai_affinity_build_sam", "ai_affinity_apply_camera",
+    "ai_ctx_mem_info",
 )
 
 
@@ -83,6 +84,7 @@ def load():
     lib.ai_last_error.restype = C.c_char_p
     lib.ai_ctx_create.argtypes = [C.c_int, P(vp)]
     lib.ai_ctx_destroy.argtypes = [vp]
+    lib.ai_ctx_mem_info.argtypes = [vp, P(i64)]
     lib.ai_affinity_build.argtypes = [vp, vp, i64, vp, i32, vp, i32, dbl, dbl, dbl, dbl, C.c_int, P(vp)]
     lib.ai_affinity_build_sam.argtypes = [vp, vp, i64, vp, i32, vp, i32, vp, i32, dbl, dbl, dbl, dbl, dbl, C.c_int, P(vp)]
     lib.ai_affinity_apply_camera.argtypes = [vp, vp, vp, i32, vp, i32, dbl, dbl, C.c_int]

@@ -22,6 +22,7 @@ void ai_set_current_arena(ai_arena* a) { g_arena = a; }
 
 void* ai_arena::alloc(size_t bytes) {
   bytes = (bytes + 255) & ~(size_t)255;
+  need += bytes;
   // first block, from the current one on, that still has room
   for (size_t b = cur; b < blocks.size(); ++b) {
     const size_t o = (b == cur) ? off : 0;
@@ -38,6 +39,17 @@ void* ai_arena::alloc(size_t bytes) {
   cur = blocks.size() - 1;
   off = bytes;
   return nb.base;
+}
+
+void ai_arena::consolidate() {
+  if (blocks.size() <= 1) return;
+  const size_t want = need_max + need_max / 16 + ((size_t)16 << 20);
+  for (auto& b : blocks) (void)hipFree(b.base);
+  blocks.clear();
+  cur = off = 0;
+  Block nb;
+  nb.cap = want > min_block ? want : min_block;
+  if (hipMalloc((void**)&nb.base, nb.cap) == hipSuccess) blocks.push_back(nb);  // on failure the call's own requests report it
 }
 
 void ai_arena::release_all() {
@@ -158,6 +170,21 @@ void ai_register_graph(ai_ctx* ctx, ai_csr* g) {
   g->owner = ctx;
   std::lock_guard<std::mutex> lock(ctx->graphs_mu);
   ctx->live_graphs.push_back(g);
+}
+
+extern "C" int ai_ctx_mem_info(ai_ctx* ctx, int64_t out[4]) {
+  if (!ctx || !out) {
+    ai_set_error("ai_ctx_mem_info: null argument");
+    return AI_ERR_BAD_ARG;
+  }
+  out[0] = (int64_t)ctx->arena.capacity();
+  out[1] = (int64_t)ctx->arena.blocks.size();
+  std::lock_guard<std::mutex> lock(ctx->graphs.mu);
+  size_t live = 0;
+  for (const auto& b : ctx->graphs.live) live += b.cap;
+  out[2] = (int64_t)live;
+  out[3] = (int64_t)ctx->graphs.cached_bytes;
+  return AI_OK;
 }
 
 extern "C" int ai_ctx_destroy(ai_ctx* ctx) {

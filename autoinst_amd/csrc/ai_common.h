@@ -41,8 +41,22 @@ struct ai_arena {
   std::vector<Block> blocks;
   size_t cur = 0, off = 0;
   size_t min_block = (size_t)256 << 20;
-  void* alloc(size_t bytes);  // nullptr on out-of-memory
-  void rewind() { cur = 0, off = 0; }
+  size_t need = 0, need_max = 0;  // bytes handed out by the running call / by the largest call so far
+  void* alloc(size_t bytes);      // nullptr on out-of-memory
+  void rewind() {
+    if (need > need_max) need_max = need;
+    need = 0, cur = 0, off = 0;
+  }
+  // A call that does not fit the blocks it finds appends one, and calls of different shapes leave a list whose sum
+  // is well above what any one of them needs.  At the START of a call (nothing of this context is in flight on the
+  // arena: every call drains its streams' use of it before it returns, and hipFree waits for the device anyway) such a
+  // list is replaced by one block of the largest need seen + 6 %.
+  void consolidate();
+  size_t capacity() const {
+    size_t t = 0;
+    for (const auto& b : blocks) t += b.cap;
+    return t;
+  }
   void release_all();
 };
 ai_arena* ai_current_arena();             // arena of the API call running on this thread (or nullptr)
@@ -51,7 +65,10 @@ void ai_set_current_arena(ai_arena* a);
 struct ArenaScope {
   ai_arena* prev;
   explicit ArenaScope(ai_arena* a) : prev(ai_current_arena()) {
-    if (a) a->rewind();
+    if (a) {
+      a->rewind();
+      a->consolidate();
+    }
     ai_set_current_arena(a);
   }
   ~ArenaScope() {

@@ -44,6 +44,12 @@ class Context:
         self._h = h
         self.device = int(device)
 
+    def mem_info(self) -> dict:
+        """Device memory the context holds between calls (``ai_ctx_mem_info``), in bytes."""
+        out = (C.c_int64 * 4)()
+        _ffi.check(_ffi.load().ai_ctx_mem_info(self._h, out), "ai_ctx_mem_info")
+        return {"workspace": out[0], "workspace_blocks": out[1], "graphs_live": out[2], "graphs_kept": out[3]}
+
     def close(self):
         if getattr(self, "_h", None):
             _ffi.load().ai_ctx_destroy(self._h)

@@ -46,6 +46,13 @@ const char* ai_last_error(void);
 
 int ai_ctx_create(int device, ai_ctx** out);
 int ai_ctx_destroy(ai_ctx* ctx);
+/*
+ * Device memory a context holds between calls (no reference counterpart: the reference's arrays are NumPy's).
+ * out[0] = bytes of the call workspace (one block once the largest call has been seen: a longer list of blocks is replaced
+ * by one of the peak need + 6 % at the start of the next call), out[1] = its number of blocks, out[2] = bytes of graphs
+ * handed out and not yet freed, out[3] = bytes of freed graph buffers kept for re-use.
+ */
+int ai_ctx_mem_info(ai_ctx* ctx, int64_t out[4]);
 
 /*
  * Affinity build.  Replaces pipeline/ncuts/ncuts_utils.py:60-67 (cdist + radius mask +

@@ -200,6 +200,48 @@ def test_run_to_run_reproducible(api):
     assert len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b))
 
 
+def test_repeated_calls_freeze_every_segment_at_the_same_size_of_T(api):
+    """The sizes of T at which a segment is judged are a function of its own history, not of timing: over repeated calls the
+    labels AND the work counter (sum over solves of rows x Lanczos steps) are identical.  (Round 3 found the convergence check
+    reading its pool entry through the scalar cache: once in ~50 000 solves the waves of a block disagreed on the segment and
+    the solve froze at another size of T; `tools/soak_trace.py` is the long version of this test.)"""
+    from autoinst_amd import synth
+    chunks = [synth.synthetic_chunk(n, seed, tarl=True) for n, seed in ((30000, 1), (24000, 2), (30000, 3), (18000, 4))]
+    first = None
+    for r in range(25):
+        graphs = [api.build_affinity(c["points"], c["tarl"], alpha=1.0, theta=0.5, gamma=0.0) for c in chunks]
+        labs, ngs, st = api.ncuts_labels_batch(graphs, None, 0.03)
+        for g in graphs:
+            g.free()
+        cur = (labs, ngs, st["spmv_rows"], st["spmv_nnz"], st["lanczos_solves"], st["max_resid"])
+        if first is None:
+            first = cur
+            continue
+        assert cur[2:] == first[2:], (r, cur[2:], first[2:])
+        assert cur[1] == first[1] and all(np.array_equal(a, b) for a, b in zip(cur[0], first[0]))
+
+
+@pytest.mark.gpu
+def test_workspace_settles_in_one_block(api):
+    """ai_ctx_mem_info: calls of growing size append workspace blocks; the next call starts by replacing the list with one
+    block of the largest need seen, and the results do not change."""
+    from autoinst_amd import synth
+    ctx = api.Context()
+    chunks = [synth.synthetic_chunk(n, seed, tarl=True) for n, seed in ((5000, 1), (40000, 2), (12000, 3))]
+    labs = []
+    for c in chunks + chunks[:1]:
+        g = api.build_affinity(c["points"], c["tarl"], alpha=1.0, theta=0.5, gamma=0.0, ctx=ctx)
+        labs.append(api.ncuts_labels(g, g.n, 0.03)[0])
+        g.free()
+    info = ctx.mem_info()
+    assert info["workspace_blocks"] == 1 and info["workspace"] > 0 and info["graphs_live"] == 0 and info["graphs_kept"] > 0
+    assert np.array_equal(labs[0], labs[3])
+    ref = api.ncuts_labels(api.build_affinity(chunks[1]["points"], chunks[1]["tarl"], alpha=1.0, theta=0.5, gamma=0.0), 40000, 0.03)[0]
+    assert np.array_equal(labs[1], ref)
+    ctx.close()
+
+
+@pytest.mark.gpu
 def test_batched_chunks_equal_separate_calls(api):
     """ai_ncut_batch: several chunks as root segments of one frontier give each chunk's own result."""
     from autoinst_amd import synth
