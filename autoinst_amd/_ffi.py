@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libautoinst_hip.so")
+LIB_PATH = os.environ.get("AUTOINST_HIP_LIB") or os.path.join(_HERE, "libautoinst_hip.so")   # the override is for A/B runs of two builds
 
 AI_OK = 0
 AI_MEM_HOST, AI_MEM_DEVICE = 0, 1
