@@ -40,10 +40,29 @@ __global__ __launch_bounds__(AI_BLOCK) void k_comp_map(const int32_t* __restrict
   if (d >= 0) orig_sub[d] = orig[i];
 }
 
+// rn[i] = 1 / ||row i of out|| (one block per row; fixed summation order)
+__global__ __launch_bounds__(AI_BLOCK) void k_row_rnorm(const double* __restrict__ out, int32_t n, double* __restrict__ rn) {
+  __shared__ double sm[AI_BLOCK / 64];
+  const double* src = out + (size_t)blockIdx.x * n;
+  double a = 0.0;
+  for (int r = threadIdx.x; r < n; r += AI_BLOCK) a = fma(src[r], src[r], a);
+  const double t = ai_block_sum(a, sm);
+  if (threadIdx.x == 0) rn[blockIdx.x] = 1.0 / sqrt(t);
+}
+// full[i][orig[r]] = out[i][r] * rn[i]
+__global__ __launch_bounds__(AI_BLOCK) void k_scatter_rows(const double* __restrict__ out, const double* __restrict__ rn,
+                                                           const int32_t* __restrict__ orig, int32_t n, size_t n_full, double* __restrict__ full) {
+  const int r = blockIdx.x * AI_BLOCK + threadIdx.x;
+  if (r >= n) return;
+  const int i = blockIdx.y;
+  full[(size_t)i * n_full + orig[r]] = out[(size_t)i * n + r] * rn[i];
+}
+
 // eigenpairs 2 .. k1+1 of ONE connected graph: k1 (lambda, unit vector) pairs, vectors scattered into
 // full-length rows of `vecs` (row stride n_full) at the positions csr->orig names
+// (`direct`: host rows of n_full doubles that receive the vectors instead of `vecs` -- the one-component case, no staging copy)
 int eigs_connected(ai_ctx* ctx, const ai_csr* csr, const ai_ncut_opts* opts, int k1, int64_t n_full, std::vector<double>& lambdas,
-                   std::vector<double>& vecs, int* steps_out, double* max_resid) {
+                   std::vector<double>& vecs, int* steps_out, double* max_resid, double* direct = nullptr) {
   Solver S(ctx, csr);
   fill_opts(S, opts);
   const int n = (int)csr->n;
@@ -75,21 +94,28 @@ int eigs_connected(ai_ctx* ctx, const ai_csr* csr, const ai_ncut_opts* opts, int
     AI_TRY(S.lanczos_fro(k1, thetas, resids, out.p, (size_t)n, &steps));
   }
   const int got = (int)thetas.size();
-  std::vector<double> h_out((size_t)got * n);
-  std::vector<int32_t> h_orig(n);
-  AI_HIP(hipMemcpyAsync(h_out.data(), out.p, h_out.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-  AI_HIP(hipMemcpyAsync(h_orig.data(), S.orig, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-  AI_HIP(hipStreamSynchronize(st));
-  vecs.assign((size_t)got * n_full, 0.0);
+  // unit vectors at the caller's row positions, formed on the device: one transfer, no host pass over k1 x n doubles
+  DevBuf<double> rn, full;
+  AI_TRY(rn.alloc((size_t)std::max(got, 1)));
+  AI_TRY(full.alloc((size_t)std::max(got, 1) * (size_t)n_full));
+  if (got > 0) {
+    if (n_full != n) AI_HIP(hipMemsetAsync(full.p, 0, (size_t)got * (size_t)n_full * sizeof(double), st));
+    hipLaunchKernelGGL(k_row_rnorm, dim3((unsigned)got), dim3(AI_BLOCK), 0, st, (const double*)out.p, (int32_t)n, rn.p);
+    AI_KERNEL_CHECK();
+    hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)((n + AI_BLOCK - 1) / AI_BLOCK), (unsigned)got), dim3(AI_BLOCK), 0, st, (const double*)out.p,
+                       (const double*)rn.p, S.orig, (int32_t)n, (size_t)n_full, full.p);
+    AI_KERNEL_CHECK();
+    double* dst = direct;
+    if (!dst) {
+      vecs.resize((size_t)got * n_full);
+      dst = vecs.data();
+    }
+    AI_HIP(hipMemcpyAsync(dst, full.p, (size_t)got * (size_t)n_full * sizeof(double), hipMemcpyDeviceToHost, st));
+    AI_HIP(hipStreamSynchronize(st));
+  }
   for (int i = 0; i < got; ++i) {
     lambdas.push_back(1.0 - thetas[i]);
     if (max_resid) *max_resid = std::max(*max_resid, resids[i]);
-    const double* src = &h_out[(size_t)i * n];
-    double n2 = 0.0;
-    for (int r = 0; r < n; ++r) n2 += src[r] * src[r];
-    const double rn = 1.0 / sqrt(n2);
-    double* dst = &vecs[(size_t)i * n_full];
-    for (int r = 0; r < n; ++r) dst[h_orig[r]] = src[r] * rn;
   }
   if (steps_out) *steps_out = std::max(*steps_out, steps);
   return AI_OK;
@@ -125,7 +151,7 @@ extern "C" int ai_eigs_smallest(ai_ctx* ctx, const ai_csr* csr, int32_t k, const
     if (h_parent[i] == i) roots.push_back(i);
   const int ncomp = (int)roots.size();
   const int nzero = std::min(ncomp, (int)k);
-  memset(evecs, 0, (size_t)k * n * sizeof(double));
+  memset(evecs, 0, (size_t)nzero * n * sizeof(double));  // the rows of the non-zero pairs are written whole below
   if (iters) *iters = 0;
   if (max_resid) *max_resid = 0.0;
   // zero pairs: the first min(k, components) components in row order (any k of them are a valid answer)
@@ -155,6 +181,7 @@ extern "C" int ai_eigs_smallest(ai_ctx* ctx, const ai_csr* csr, int32_t k, const
   std::vector<std::vector<double>> cvecs(ncomp);
   int steps = 0;
   double mr = 0.0;
+  bool placed = false;
   for (int c = 0; c < ncomp; ++c) {
     ai_csr sub;
     const ai_csr* use = csr;
@@ -200,17 +227,25 @@ extern "C" int ai_eigs_smallest(ai_ctx* ctx, const ai_csr* csr, int32_t k, const
       use = &sub;
     }
     std::vector<double> lam;
-    AI_TRY(eigs_connected(ctx, use, opts, need, n, lam, cvecs[c], &steps, &mr));
+    // one component: its pairs come out in ascending order and go straight into the caller's rows
+    double* direct = (ncomp == 1 && need <= n - 1) ? evecs + (size_t)nzero * n : nullptr;
+    AI_TRY(eigs_connected(ctx, use, opts, need, n, lam, cvecs[c], &steps, &mr, direct));
+    if (direct && (int)lam.size() == need) {
+      for (int i = 0; i < need; ++i) evals[nzero + i] = lam[i];
+      placed = true;
+    }
     for (int i = 0; i < (int)lam.size(); ++i) cands.push_back(Cand{lam[i], c, i});
   }
   if ((int)cands.size() < need) {
     ai_set_error("ai_eigs_smallest: only %zu of %d eigenpairs could be formed", cands.size() + (size_t)nzero, k);
     return AI_ERR_NO_CONVERGENCE;
   }
-  std::stable_sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.lambda < b.lambda; });
-  for (int i = 0; i < need; ++i) {
-    evals[nzero + i] = cands[i].lambda;
-    memcpy(evecs + (size_t)(nzero + i) * n, &cvecs[cands[i].comp][(size_t)cands[i].idx * n], (size_t)n * sizeof(double));
+  if (!placed) {
+    std::stable_sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.lambda < b.lambda; });
+    for (int i = 0; i < need; ++i) {
+      evals[nzero + i] = cands[i].lambda;
+      memcpy(evecs + (size_t)(nzero + i) * n, &cvecs[cands[i].comp][(size_t)cands[i].idx * n], (size_t)n * sizeof(double));
+    }
   }
   if (iters) *iters = steps;
   if (max_resid) *max_resid = mr;

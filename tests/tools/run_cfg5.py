@@ -33,7 +33,18 @@ A = g.to_scipy()
 g.free()
 nc, comp = connected_components(A, directed=False)
 idx = np.flatnonzero(comp == np.bincount(comp).argmax())
+# Rows in the order of 1 m cells along a Morton curve, as `ai_affinity_build` itself keeps a graph on the device (the export
+# above went back to the caller's point order): consecutive rows then share most of their neighbours, which is what the
+# grouped SpMM of the Chebyshev filter (k_cf_spmm_g) and the XCD-local L2 re-use of the gathered rows live on.
+if not os.environ.get("AI_CFG5_CALLER_ORDER"):
+    cell = np.floor((pts[idx] - pts[idx].min(axis=0)) / 1.0).astype(np.uint64)
+    key = np.zeros(idx.shape[0], dtype=np.uint64)
+    for b in range(21):
+        for d in range(3):
+            key |= ((cell[:, d] >> np.uint64(b)) & np.uint64(1)) << np.uint64(3 * b + d)
+    idx = idx[np.argsort(key, kind="stable")]
 sub = sp.csr_matrix(A[idx][:, idx])
+sub.sort_indices()
 del A
 N, E = sub.shape[0], sub.nnz
 print(f"largest component {N} of {n} rows ({nc} components), {E} entries", file=sys.stderr, flush=True)
