@@ -257,9 +257,10 @@ def ncuts_labels(graph: DeviceGraph, num_points_orig: int, T: float, split_lim: 
     ng = C.c_int32()
     stats = _ffi.NcutStats()
     o = _opts(tol, max_iter, check_every, time_spmv)
-    _ffi.check(_ffi.load().ai_ncut(graph.ctx._h, graph._h, int(num_points_orig), float(T), float(split_lim),
-                                   C.byref(o), lab.ctypes.data, C.byref(ng), C.byref(stats)), "ai_ncut")
-    _last_stats = stats.as_dict()
+    status = _ffi.load().ai_ncut(graph.ctx._h, graph._h, int(num_points_orig), float(T), float(split_lim),
+                                 C.byref(o), lab.ctypes.data, C.byref(ng), C.byref(stats))
+    _last_stats = stats.as_dict()   # filled on AI_ERR_NO_CONVERGENCE too
+    _ffi.check(status, "ai_ncut")
     return lab, int(ng.value), _last_stats
 
 
@@ -286,9 +287,9 @@ def ncuts_labels_batch(graphs, num_points_orig=None, T=CONFIG["T"], split_lim=SP
     ng = (C.c_int32 * k)()
     stats = _ffi.NcutStats()
     o = _opts(tol, max_iter, check_every, time_spmv, window_rows)
-    _ffi.check(_ffi.load().ai_ncut_batch(ctx._h, gh, k, no, float(T), float(split_lim), C.byref(o), lp, ng, C.byref(stats)),
-               "ai_ncut_batch")
-    _last_stats = stats.as_dict()
+    status = _ffi.load().ai_ncut_batch(ctx._h, gh, k, no, float(T), float(split_lim), C.byref(o), lp, ng, C.byref(stats))
+    _last_stats = stats.as_dict()   # filled on AI_ERR_NO_CONVERGENCE too (`last_stats()` after the exception)
+    _ffi.check(status, "ai_ncut_batch")
     return labs, [int(x) for x in ng], _last_stats
 
 
