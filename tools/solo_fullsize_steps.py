@@ -20,7 +20,7 @@ for r in range(3):
     except _ffi.NoConvergence:
         st = api.last_stats()
     for g in graphs: g.free()
-    if r:
+    if r and st["ms_spmv"] > 0:
         b = spmv_bytes(int(st["spmv_rows"]), int(st["spmv_nnz"]), int(st["lanczos_steps"]))
         out.append({"steps": st["lanczos_steps"], "spmv_ms": round(st["ms_spmv"], 2), "us_per_launch": round(1e3 * st["ms_spmv"] / max(st["lanczos_steps"], 1), 2),
                     "frac_by_counters": round(b / st["ms_spmv"] / 1e9 / 8.0, 3)})
