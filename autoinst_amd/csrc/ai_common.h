@@ -233,6 +233,18 @@ __device__ __forceinline__ double ai_block_sum(double v, double* sm /* AI_BLOCK/
   return r;
 }
 
+// the same when `sm` has not been used before in the block (no barrier in front of the write)
+__device__ __forceinline__ double ai_block_sum_first(double v, double* sm /* AI_BLOCK/64 doubles */) {
+  v = ai_wave_sum(v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  if (l == 0) sm[w] = v;
+  __syncthreads();
+  double r = 0.0;
+#pragma unroll
+  for (int i = 0; i < AI_BLOCK / 64; ++i) r += sm[i];
+  return r;
+}
+
 // Deterministic start-vector entry in (-1, 1) from the ORIGINAL point id (splitmix64 finaliser).
 // tests/gpu_model.py::start_vector is the same function.
 __device__ __forceinline__ double ai_hash_unit(uint32_t id) {
