@@ -114,7 +114,7 @@ def test_cfg3_small_map_chunk_parallel_driver(api):
     import run_cfg3
     from autoinst_amd import synth
     sizes = run_cfg3.chunk_sizes(True)
-    merged, _ = run_cfg3.run_map(sizes, 1, 0, 0, in_flight=3)
+    merged, _, _ = run_cfg3.run_map(sizes, 1, 0, 0, in_flight=3)
     assert sorted(merged) == list(range(len(sizes)))
     for i in (0, len(sizes) - 1):
         ch = synth.synthetic_chunk(sizes[i], seed=1000 + i, tarl=True)
@@ -133,7 +133,7 @@ def test_cfg3_full_map_through_run_chunks(api):
     from autoinst_amd import synth
     sizes = run_cfg3.chunk_sizes(False)
     assert len(sizes) == 72 and sum(sizes) > 2_000_000
-    merged, seconds = run_cfg3.run_map(sizes, 1, 0, 0, in_flight=2, batch=12)
+    merged, seconds, _ = run_cfg3.run_map(sizes, 1, 0, 0, in_flight=2, batch=12)
     assert sorted(merged) == list(range(72)) and all(merged[i].shape[0] == sizes[i] for i in merged)
     print("cfg3 full map:", len(sizes), "chunks,", sum(sizes), "points,", seconds, "s")
     for i in (0, 7, 19, 26, 33, 48, 57, 63, 64, 71):
