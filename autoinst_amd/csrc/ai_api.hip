@@ -166,6 +166,46 @@ extern "C" int ai_ctx_create(int device, ai_ctx** out) {
   return AI_OK;
 }
 
+void ai_helper::start() {
+  if (th.joinable()) return;
+  quit = false;
+  th = std::thread([this] {
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      cv.wait(lk, [this] { return has_job || quit; });
+      if (quit) return;
+      std::function<void()> f = std::move(job);
+      has_job = false;
+      lk.unlock();
+      f();
+      lk.lock();
+      done = true;
+      cv.notify_all();
+    }
+  });
+}
+void ai_helper::submit(std::function<void()> f) {
+  start();
+  std::lock_guard<std::mutex> lk(mu);
+  job = std::move(f);
+  has_job = true;
+  done = false;
+  cv.notify_all();
+}
+void ai_helper::wait() {
+  std::unique_lock<std::mutex> lk(mu);
+  cv.wait(lk, [this] { return done; });
+}
+void ai_helper::stop() {
+  if (!th.joinable()) return;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    quit = true;
+    cv.notify_all();
+  }
+  th.join();
+}
+
 void ai_register_graph(ai_ctx* ctx, ai_csr* g) {
   g->owner = ctx;
   std::lock_guard<std::mutex> lock(ctx->graphs_mu);
@@ -189,6 +229,7 @@ extern "C" int ai_ctx_mem_info(ai_ctx* ctx, int64_t out[4]) {
 
 extern "C" int ai_ctx_destroy(ai_ctx* ctx) {
   if (!ctx) return AI_OK;
+  ctx->helper.stop();
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (int i = 0; i < 8; ++i)

@@ -3,7 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -100,6 +103,21 @@ struct ai_graph_cache {
   void release_all();
 };
 
+// One helper thread per context for host-side work of a call that must not hold up the thread that feeds the streams (the
+// Ritz coefficients of a harvest wave: ai_flow.inc).  One job at a time; created on first use, joined with the context.
+struct ai_helper {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::function<void()> job;
+  bool has_job = false, quit = false;
+  volatile bool done = true;
+  void start();
+  void submit(std::function<void()> f);  // the previous job must have been waited for
+  void wait();
+  void stop();
+};
+
 struct ai_csr;
 struct ai_ctx {
   int device;
@@ -118,6 +136,7 @@ struct ai_ctx {
   char* stage;                         // AI_STAGE_BYTES of pinned host memory for packed small uploads / downloads
   std::mutex graphs_mu;                // guards live_graphs (a graph may be freed from another thread)
   std::vector<ai_csr*> live_graphs;    // graphs this context built and that are still alive: their buffers are the context's
+  ai_helper helper;                    // host-side helper thread (started on first use)
 };
 void ai_register_graph(ai_ctx* ctx, ai_csr* g);   // sets g->owner
 // a graph whose context was destroyed keeps a valid handle (to free) but no buffers
