@@ -22,8 +22,9 @@ SYMBOLS = (
     "ai_sweep", "ai_lsym_apply", "ai_bench_spmv", "ai_eigs_smallest",
     "ai_radius_mean_pool", "ai_nn1_project", "ai_ncut_batch",
     "ai_label_pairs", "ai_merge_associate", "ai_unique_points", "ai_affinity_build_sam", "ai_affinity_apply_camera",
-    "ai_ctx_mem_info",
+    "ai_ctx_mem_info", "ai_abi_version", "ai_abi_sizeof",
 )
+ABI_VERSION = 4   # AI_ABI_VERSION of the header this binding was written against
 
 
 class NcutOpts(C.Structure):
@@ -104,9 +105,16 @@ def load():
     lib.ai_label_pairs.argtypes = [vp, vp, vp, i64, C.c_int, i64, vp, vp, vp, P(i64)]
     lib.ai_merge_associate.argtypes = [vp, vp, vp, i64, vp, vp, i64, vp, dbl, i32, i32, C.c_int, vp, vp, vp, vp, vp]
     lib.ai_unique_points.argtypes = [vp, vp, i64, C.c_int, vp, P(i64)]
+    lib.ai_abi_sizeof.argtypes = [C.c_int]
     for name in SYMBOLS:
-        if name not in ("ai_version", "ai_last_error"):
+        if name not in ("ai_version", "ai_last_error", "ai_abi_sizeof"):
             getattr(lib, name).restype = C.c_int
+    lib.ai_abi_sizeof.restype = i64
+    # a library built from another header would read past (or short of) the structs this binding passes
+    if lib.ai_abi_version() != ABI_VERSION or lib.ai_abi_sizeof(0) != C.sizeof(NcutOpts) or lib.ai_abi_sizeof(1) != C.sizeof(NcutStats):
+        raise AutoinstHipError(
+            f"{LIB_PATH}: ABI version {lib.ai_abi_version()} / struct sizes {lib.ai_abi_sizeof(0)}, {lib.ai_abi_sizeof(1)} do not match this "
+            f"binding ({ABI_VERSION} / {C.sizeof(NcutOpts)}, {C.sizeof(NcutStats)}): rebuild the library (make -C autoinst_amd/csrc)")
     _lib = lib
     return lib
 

@@ -14,6 +14,10 @@ void ai_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* ai_last_error(void) { return g_err; }
+extern "C" int ai_abi_version(void) { return AI_ABI_VERSION; }
+extern "C" int64_t ai_abi_sizeof(int which) {
+  return which == 0 ? (int64_t)sizeof(ai_ncut_opts) : which == 1 ? (int64_t)sizeof(ai_ncut_stats) : -1;
+}
 
 // ----------------------------------------------------------------------------- arena
 static thread_local ai_arena* g_arena = nullptr;

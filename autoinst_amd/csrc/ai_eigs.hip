@@ -94,6 +94,17 @@ int eigs_connected(ai_ctx* ctx, const ai_csr* csr, const ai_ncut_opts* opts, int
     AI_TRY(S.lanczos_fro(k1, thetas, resids, out.p, (size_t)n, &steps));
   }
   const int got = (int)thetas.size();
+  // the solvers return at most k1 pairs, thetas descending (lambda = 1 - theta ascending): the direct path below writes `got` rows
+  // into the caller's array in that order without the sort of the general path, so both properties are checked, not assumed
+  if (got > k1) {
+    ai_set_error("internal: the eigensolver returned %d pairs, %d were asked for", got, k1);
+    return AI_ERR_INTERNAL;
+  }
+  for (int i = 1; i < got; ++i)
+    if (thetas[i] > thetas[i - 1]) {
+      ai_set_error("internal: the eigensolver's Ritz values are not in descending order (%.17g after %.17g at %d)", thetas[i], thetas[i - 1], i);
+      return AI_ERR_INTERNAL;
+    }
   // unit vectors at the caller's row positions, formed on the device: one transfer, no host pass over k1 x n doubles
   DevBuf<double> rn, full;
   AI_TRY(rn.alloc((size_t)std::max(got, 1)));

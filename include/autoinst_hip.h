@@ -8,7 +8,8 @@
  * sizes only -- no torch / numpy types.  All matrices are float64, like the
  * reference's arithmetic.
  *
- * Threading: an ai_ctx owns one HIP stream and is not thread-safe; the library is
+ * Threading: an ai_ctx owns its HIP streams (one for the affinity build and the Lanczos steps, one for the convergence
+ * checks, one for the harvest waves of the normalized cut) and one helper thread; it is not thread-safe, the library is
  * re-entrant across contexts.  One process per GPU for multi-GPU use.
  * Ownership: the caller owns every array it passes; nothing is retained after a
  * call returns.  Handles returned here are freed with the matching *_free/destroy.
@@ -26,6 +27,16 @@ extern "C" {
 
 typedef struct ai_ctx ai_ctx;
 typedef struct ai_csr ai_csr; /* device-resident symmetric affinity graph */
+
+/*
+ * ABI version: bumped whenever a struct of this header changes size or a field changes meaning (4: round 4; 3 added
+ * ai_ncut_opts.window_rows).  A binding checks ai_abi_version() == AI_ABI_VERSION and ai_abi_sizeof(which) against its own
+ * struct sizes when it loads the library (autoinst_amd/_ffi.py does): a caller built against an older header would otherwise
+ * pass a shorter ai_ncut_opts and have the library read past it.
+ */
+#define AI_ABI_VERSION 4
+int ai_abi_version(void);
+int64_t ai_abi_sizeof(int which); /* 0: ai_ncut_opts, 1: ai_ncut_stats; -1 otherwise */
 
 typedef enum {
   AI_OK = 0,
@@ -120,7 +131,7 @@ int ai_csr_free(ai_ctx* ctx, ai_csr* csr);
 typedef struct {
   double tol;           /* Ritz residual |beta_m s_m| at which a Lanczos solve stops (default 1e-10) */
   int32_t max_iter;     /* Lanczos step cap per solve (default 4000; larger values are clamped to 4000: the convergence check keeps T_m in 64 KB of LDS) */
-  int32_t check_every;  /* steps between convergence checks on large segments (default 16) */
+  int32_t check_every;  /* size of T at a solve's FIRST convergence check (default 16, at most 64); later checks are placed by the residual trend, 4 .. 48 steps apart */
   int32_t reserved;     /* profiling, fills ms_spmv (for bench.py): bit 0 or 1 = every SpMV launch stamps its own span (first block in .. last block out) on the device clock, which does not perturb how launches of several streams overlap */
   int64_t window_rows;  /* ai_ncut_batch: rows (points) of the chunks that iterate at one time; further chunks of the call are admitted as earlier ones finish, so the Lanczos vector storage is sized for the window, not for the call (0 = 4 800 000; never less than the call's largest chunk) */
 } ai_ncut_opts;
@@ -193,9 +204,9 @@ int ai_lsym_apply(ai_ctx* ctx, const ai_csr* csr, const double* x, double* y);
  * Every connected component contributes one zero eigenvalue with eigenvector D^1/2 1_C / sqrt(vol_C)
  * (formed explicitly).  With >= k components the answer is k such pairs (any k of them are a
  * valid answer, as with SciPy).  Otherwise the remaining pairs are the smallest non-zero ones of the
- * union of the components' spectra: each component is solved on its own by Lanczos with full
- * re-orthogonalisation (stops when the innermost wanted pair's Ritz residual <= opts->tol) and
- * the results are merged.
+ * union of the components' spectra: each component is solved on its own -- by Chebyshev-filtered subspace iteration
+ * (n >= 1024 and >= 3 pairs wanted; stops when the true residuals of the first k - 1 pairs are <= opts->tol), else by Lanczos
+ * with full re-orthogonalisation (stops when the innermost wanted pair's Ritz residual <= opts->tol) -- and the results are merged.
  */
 int ai_eigs_smallest(ai_ctx* ctx, const ai_csr* csr, int32_t k, const ai_ncut_opts* opts, double* evals,
                      double* evecs, int32_t* iters, double* max_resid);

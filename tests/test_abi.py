@@ -32,6 +32,21 @@ def test_stats_struct_layout_matches_header():
     assert names == [f for f, _ in _ffi.NcutStats._fields_]
 
 
+def test_abi_version_and_struct_sizes():
+    """The library reports the header's ABI version and struct sizes; the binding's ctypes structs have the same sizes
+    (a caller built against an older header would pass a shorter ai_ncut_opts)."""
+    import ctypes as C
+    lib = _ffi.load()
+    txt = open(os.path.join(ROOT, "include", "autoinst_hip.h")).read()
+    assert int(re.search(r"#define AI_ABI_VERSION (\d+)", txt).group(1)) == lib.ai_abi_version() == _ffi.ABI_VERSION
+    assert lib.ai_abi_sizeof(0) == C.sizeof(_ffi.NcutOpts) == 32
+    assert lib.ai_abi_sizeof(1) == C.sizeof(_ffi.NcutStats)
+    assert lib.ai_abi_sizeof(7) == -1
+    body = re.search(r"typedef struct \{([^}]*)\} ai_ncut_opts;", txt, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    assert re.findall(r"(?:int64_t|int32_t|double)\s+([a-z_0-9]+)\s*;", body) == [f for f, _ in _ffi.NcutOpts._fields_]
+
+
 def test_no_cpu_fallback_without_gpu():
     """Without a device the product raises instead of computing somewhere else."""
     import torch

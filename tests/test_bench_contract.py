@@ -32,7 +32,7 @@ def test_committed_bench_line_has_the_contract_fields():
     if "r01" not in _newest_bench_line() and "r02" not in _newest_bench_line():
         # since round 3: the pool is min(host cores, 128) workers and says which host the cached full-size run came from
         assert c["pool"]["cores"] == min(c["pool"]["host_cores_available"], 128) and "cpu_model" in c["cached_host"]
-        assert r["kernel"] == "fk_spmv" and r["traffic"] is None or r["traffic"] > 0
+        assert r["kernel"] == "fk_spmv" and (r["traffic"] is None or r["traffic"] > 0)
 
 
 def test_bench_launches_its_own_ranks_dry():

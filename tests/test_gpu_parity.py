@@ -283,6 +283,51 @@ def test_admission_window_and_many_chunks_in_one_call(api):
 
 
 @pytest.mark.gpu
+def test_hundreds_of_chunks_in_one_call_and_children_that_wait_for_a_slot(api, monkeypatch, capfd):
+    """Admission is slot-aware (round-3 advisor finding): a call whose live segments outnumber the Lanczos slots / pool records it
+    was set up with lets children wait for a slot instead of failing with an internal error.  (i) 600 small chunks in ONE call;
+    (ii) the same labels when the call has only 48 slots (AI_FLOW_SMAX: every wave defers children); (iii) chunks whose
+    num_points_orig is far below their size, so that the 1 % rule allows thousands of live segments."""
+    from autoinst_amd import synth
+    rng = np.random.default_rng(11)
+    sizes = [int(x) for x in np.exp(rng.uniform(np.log(1500), np.log(5000), 600))]
+    chunks = [synth.synthetic_chunk(n, 500 + i, tarl=False) for i, n in enumerate(sizes)]
+    graphs = [api.build_affinity(c["points"], None, alpha=1.0, theta=0.0, gamma=0.0) for c in chunks]
+    labs, ngs, st = api.ncuts_labels_batch(graphs, None, 0.075)
+    assert st["unconverged"] == 0 and len(labs) == 600
+    for i in (0, 17, 311, 599):
+        l1, n1, _ = api.ncuts_labels(graphs[i], graphs[i].n, 0.075)
+        assert n1 == ngs[i] and np.array_equal(l1, labs[i])
+    # (ii) 40 of them with 48 slots: labels unchanged, children waited
+    sub = graphs[:40]
+    ref = [labs[i] for i in range(40)]
+    monkeypatch.setenv("AI_FLOW_SMAX", "48")
+    monkeypatch.setenv("AI_NCUT_PHASES", "1")
+    capfd.readouterr()
+    labs48, ngs48, st48 = api.ncuts_labels_batch(sub, None, 0.075)
+    err = capfd.readouterr().err
+    monkeypatch.delenv("AI_FLOW_SMAX")
+    monkeypatch.delenv("AI_NCUT_PHASES")
+    import re
+    waited = int(re.search(r"children that waited for a slot (\d+)", err).group(1))
+    assert waited > 0, err
+    assert ngs48 == ngs[:40] and all(np.array_equal(a, b) for a, b in zip(labs48, ref))
+    # (iii) num_points_orig = 1 % of the size: segments down to 0.01 % of the chunk stay eligible
+    big = graphs[:8]
+    norig = [max(1, g.n // 100) for g in big]
+    labs_s, ngs_s, st_s = api.ncuts_labels_batch(big, norig, 0.075)
+    assert st_s["unconverged"] == 0
+    for g, lab, ng in zip(big, labs_s, ngs_s):
+        assert lab.shape == (g.n,) and lab.min() == 0 and lab.max() == ng - 1 and len(np.unique(lab)) == ng
+    monkeypatch.setenv("AI_FLOW_SMAX", "32")
+    labs_t, ngs_t, _ = api.ncuts_labels_batch(big, norig, 0.075)
+    monkeypatch.delenv("AI_FLOW_SMAX")
+    assert ngs_t == ngs_s and all(np.array_equal(a, b) for a, b in zip(labs_t, labs_s))
+    for g in graphs:
+        g.free()
+
+
+@pytest.mark.gpu
 def test_level_synchronous_driver_gives_the_same_labels(tmp_path):
     """AI_NCUT_LOCKSTEP=1 (the level-synchronous driver, kept for A/B measurements) and the asynchronous frontier give
     identical labels: same solver arithmetic per segment, same sweep, same emission order."""
