@@ -22,7 +22,7 @@ SYMBOLS = (
     "ai_sweep", "ai_lsym_apply", "ai_bench_spmv", "ai_eigs_smallest",
     "ai_radius_mean_pool", "ai_nn1_project", "ai_ncut_batch",
     "ai_label_pairs", "ai_merge_associate", "ai_unique_points", "ai_affinity_build_sam", "ai_affinity_apply_camera",
-    "ai_ctx_mem_info", "ai_abi_version", "ai_abi_sizeof",
+    "ai_ctx_mem_info", "ai_abi_version", "ai_abi_sizeof", "ai_bench_copy",
 )
 ABI_VERSION = 4   # AI_ABI_VERSION of the header this binding was written against
 
@@ -106,6 +106,7 @@ def load():
     lib.ai_merge_associate.argtypes = [vp, vp, vp, i64, vp, vp, i64, vp, dbl, i32, i32, C.c_int, vp, vp, vp, vp, vp]
     lib.ai_unique_points.argtypes = [vp, vp, i64, C.c_int, vp, P(i64)]
     lib.ai_abi_sizeof.argtypes = [C.c_int]
+    lib.ai_bench_copy.argtypes = [vp, i64, i32, P(dbl)]
     for name in SYMBOLS:
         if name not in ("ai_version", "ai_last_error", "ai_abi_sizeof"):
             getattr(lib, name).restype = C.c_int

@@ -378,6 +378,13 @@ def bench_spmv(graph: DeviceGraph, reps=50):
     return float(ms.value), float(by.value)
 
 
+def bench_copy(ctx: "Context", nbytes=1 << 30, reps=10):
+    """GB/s (read + written) of a plain device-to-device copy with 16-byte accesses: the box's stream rate."""
+    g = C.c_double()
+    _ffi.check(_ffi.load().ai_bench_copy(ctx._h, int(nbytes), int(reps), C.byref(g)), "ai_bench_copy")
+    return float(g.value)
+
+
 # --------------------------------------------------------------------------- reference call surface
 def ncuts_chunk(dataset, chunk_downsample_dict, pcd_nonground_minor, T_pcd, sampled_indices_global,
                 sequence=None, patchwise_indices=None):

@@ -28,7 +28,8 @@ Rank 0 prints ONE JSON line.
 * `cpu_baseline` is the oracle (NumPy / SciPy restatement, scipy eigsh shift-invert as the reference):
   `value` = the MEASURED single-process run on the full 200k chunk (cached in `profiles/`, it takes hours; `cached_host`
   says where it ran), `pool` = a process pool of min(host cores, 128) workers on THIS host over 20k-26k-point chunks,
-  timed now (`--cpu-50k` adds one single-process 50k-point run on this host, ~3 min).
+  timed now, and one single-process 50k-point run on this host (~2-3 min; skipped when the pool leg took more than 200 s
+  unless `--cpu-50k`, never with `--no-cpu-50k`).
 * `value_host_inputs` = the same loop with the inputs in pinned host memory, sent on a copy stream per host thread
   one batch ahead of its kernels; `value` has them resident in HBM.
 * `single_chunk_latency_ms` and the per-chunk counters are those of the seed-0 chunk alone; `single_chunk_latency_ms_all`
@@ -111,7 +112,7 @@ def _cpu_one_worker(job):
     return _cpu_pool_worker(job)
 
 
-def cpu_baseline(workers: int | None = None, with_50k: bool = False):
+def cpu_baseline(workers: int | None = None, with_50k: bool | None = None):
     """The oracle beside the GPU number.
 
     (i) `value`: the single-process oracle on the real 200k chunk, measured once in the build container by
@@ -133,6 +134,8 @@ def cpu_baseline(workers: int | None = None, with_50k: bool = False):
         res = pool.map(_cpu_pool_worker, jobs, chunksize=1)
     wall = time.perf_counter() - t0
     same_box = None
+    if with_50k is None:   # default: yes, unless the pool leg already took long (a slow or heavily shared host)
+        with_50k = wall <= 200.0
     if with_50k:   # one single-process run at 50k points on THIS host (the oracle grows faster than linearly in N)
         with ctx.Pool(1) as pool:
             n50, sec50, g50 = pool.map(_cpu_one_worker, [(50_000, 0)])[0]
@@ -165,6 +168,41 @@ def cpu_baseline(workers: int | None = None, with_50k: bool = False):
         out.update({"value": pool_info["points_per_sec"] / N_POINTS, "cores": workers, "measured": False, "extrapolated": True,
                     "sample": pool_info["sample"] + f"; points/s scaled linearly to {N_POINTS}-point chunks (flatters the CPU)"})
     return out
+
+
+# ----------------------------------------------------------------------------- host placement (host-input leg)
+def _parse_cpulist(txt: str):
+    cpus = set()
+    for part in txt.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def gpu_numa_cpus(torch, index: int):
+    """(NUMA node of GPU `index`, CPUs of that node this process may run on, note).  The pinned staging blocks of the host-input
+    leg are first touched, and the loader thread that sends them runs, on those CPUs: pinned memory on the far socket halves
+    the H2D rate and the copy then no longer hides behind the kernels (round 3: 0.98 of the resident rate on the builder's
+    boxes, 0.795 on the driver's)."""
+    allowed = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else set(range(os.cpu_count() or 1))
+    try:
+        pr = torch.cuda.get_device_properties(index)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read().strip())
+    except (OSError, ValueError, AttributeError) as e:
+        return None, set(allowed), f"GPU NUMA node unknown ({type(e).__name__})"
+    if node < 0:
+        return node, set(allowed), "the platform reports no NUMA node for the GPU"
+    try:
+        node_cpus = _parse_cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read())
+    except OSError:
+        return node, set(allowed), "node cpulist unreadable"
+    near = node_cpus & set(allowed)
+    if not near:
+        return node, set(allowed), f"none of this process's {len(allowed)} CPUs is on the GPU's node {node}"
+    return node, near, f"{len(near)} of this process's {len(allowed)} CPUs are on the GPU's node {node}"
 
 
 # ----------------------------------------------------------------------------- self-launch
@@ -271,7 +309,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--in-flight", type=int, default=2, help="host threads (contexts) per GPU")
     ap.add_argument("--batch", type=int, default=12, help="chunks per batched call (their segments iterate in one pool)")
-    ap.add_argument("--cpu-50k", action="store_true", help="cpu_baseline: also one single-process 50k-point oracle run on this host (~3 min)")
+    ap.add_argument("--cpu-50k", action="store_true", help="cpu_baseline: the single-process 50k-point oracle run on this host (~3 min) even when the pool leg took more than 200 s")
+    ap.add_argument("--no-cpu-50k", action="store_true", help="cpu_baseline: skip the single-process 50k-point oracle run on this host")
     ap.add_argument("--batches", type=int, default=0, help="batched calls per GPU per step (default: one per host thread)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-inputs", action="store_true", help="skip the pinned-host-input leg (value_host_inputs)")
@@ -331,14 +370,20 @@ def main():
     # kernels of the K batches in flight.  (tools/probe_h2d_interference.py: copies queued back to back on a stream cost the
     # kernels beside them 27 %, one copy at a time 1-4 %.)
     host_blocks, stage_blocks, views = [], [], None
+    numa_node, near_cpus, numa_note = None, None, None
+    h2d = {"bytes": 0, "seconds": 0.0, "copies": 0, "wait_block_seconds": 0.0}
     if host:
         np_, nf_ = host[0][0].size, host[0][1].size
+        numa_node, near_cpus, numa_note = gpu_numa_cpus(torch, local_rank)
+        all_cpus = os.sched_getaffinity(0)
+        os.sched_setaffinity(0, near_cpus)   # first touch of the pinned blocks on the GPU's node (this thread only; restored below)
         for k in range(M):
             blk = torch.empty(B * (np_ + nf_), dtype=torch.float64).pin_memory()
             for b, (p, f) in enumerate(host[k * B:(k + 1) * B]):
                 blk[b * np_:(b + 1) * np_] = torch.from_numpy(p).reshape(-1)
                 blk[B * np_ + b * nf_:B * np_ + (b + 1) * nf_] = torch.from_numpy(f).reshape(-1)
             host_blocks.append(blk)
+        os.sched_setaffinity(0, all_cpus)
         shp_p, shp_f = host[0][0].shape, host[0][1].shape
         host = True
         stage_blocks = [torch.empty(B * (np_ + nf_), dtype=torch.float64, device=dev) for _ in range(K + 1)]
@@ -381,15 +426,24 @@ def main():
     uploads = queue.Queue()    # host-input jobs on their way to `work`
 
     def loader():
+        if near_cpus:
+            os.sched_setaffinity(0, near_cpus)   # (pid 0 = the calling thread)
         cs = torch.cuda.Stream(device=dev)
         while True:
             job = uploads.get()
             if job is None:
                 return
+            t_w = time.perf_counter()
             i = free_blocks.get()
+            t_c = time.perf_counter()
             with torch.cuda.stream(cs):
                 stage_blocks[i].copy_(host_blocks[job[1]], non_blocking=True)
             cs.synchronize()
+            t_e = time.perf_counter()
+            h2d["bytes"] += host_blocks[job[1]].numel() * 8
+            h2d["seconds"] += t_e - t_c
+            h2d["wait_block_seconds"] += t_c - t_w
+            h2d["copies"] += 1
             work.put(job + (i,))
 
     def worker(w):
@@ -475,11 +529,27 @@ def main():
     stb = res[0][2]
 
     # ---- the same loop with the inputs in pinned host memory (the library copies them on the context's stream)
-    host_steps, elapsed_host, hbm_host_leg = 0, None, None
+    host_steps, elapsed_host, hbm_host_leg, host_leg = 0, None, None, None
     if host:
         host_steps = args.steps   # as many as the resident leg: the first batch of each thread has nothing to hide its transfer behind
+        # the link alone: one batch's block, nothing else on the device
+        torch.cuda.synchronize()
+        t_a = time.perf_counter()
+        for _ in range(3):
+            stage_blocks[0].copy_(host_blocks[0], non_blocking=True)
+            torch.cuda.synchronize()
+        h2d_alone_gbps = 3 * host_blocks[0].numel() * 8 / (time.perf_counter() - t_a) / 1e9
         run_steps(1, from_host=True)
+        h2d.update({"bytes": 0, "seconds": 0.0, "copies": 0, "wait_block_seconds": 0.0})
         elapsed_host, _ = timed(host_steps, from_host=True)
+        host_leg = {
+            "gpu_numa_node": numa_node, "placement": numa_note, "loader_cpus": len(near_cpus) if near_cpus else None,
+            "h2d_gbps_alone": h2d_alone_gbps,                                   # one 1.9 GB copy at a time, idle device
+            "h2d_gbps_in_leg": h2d["bytes"] / max(h2d["seconds"], 1e-9) / 1e9,  # the same copies beside the kernels of the batches in flight
+            "loader_copy_frac": h2d["seconds"] / elapsed_host,                  # share of the leg's wall time the loader spent copying
+            "loader_wait_for_staging_block_frac": h2d["wait_block_seconds"] / elapsed_host,   # ... waiting for a free staging block (the kernels are the limit)
+            "copies": h2d["copies"], "bytes_per_copy": h2d["bytes"] // max(h2d["copies"], 1),
+        }
         # the leg's device staging ring (K + 1 blocks of one batch's inputs) exists only for this leg
         free_with_ring, _tot = torch.cuda.mem_get_info(dev)
         hbm_host_leg = (_tot - free_with_ring) / 1e9
@@ -533,6 +603,8 @@ def main():
     torch.cuda.synchronize()
     copy_gbps = 10 * 2 * src.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
     del src, dst
+    torch.cuda.empty_cache()
+    copy16_gbps = api.bench_copy(ctxs[0], 1 << 30, 10)   # the library's own float4 copy kernel (the guide measures 6.29 TB/s for one)
     barrier()
     for _ in range(K):
         work.put(None)
@@ -570,8 +642,10 @@ def main():
                        "n_points": N_POINTS, "nnz": int(nnz), "chunks_per_step": world * M * B, "threads_per_gpu": K, "chunks_per_batch": B, "batches_per_step": M,
                        "parallelism": f"chunk-dp{world}"},
             "value_host_inputs": (world * M * B * host_steps / elapsed_host) if elapsed_host else None,
+            "host_inputs_ratio": (elapsed * host_steps / (elapsed_host * args.steps)) if elapsed_host else None,   # value_host_inputs / value
             "host_inputs_note": "same loop, each batch's points + features in one pinned host block (159 MB per chunk), sent by a loader thread with one copy per batch into a ring of three device staging blocks, one batch ahead of the kernels"
                                 if elapsed_host else None,
+            "host_inputs": host_leg,   # where the pinned blocks and the loader thread ran, the link's rate alone and in the leg, what the loader waited for
             "hbm_in_use_gb": (total_b - free_b) / 1e9,   # inputs + K workspaces (arena, cached graph buffers) + torch
             "hbm_in_use_host_inputs_gb": hbm_host_leg,   # the same + the host-input leg's staging ring
             "single_chunk_latency_ms": latency_ms,   # the seed-0 chunk (per-chunk counters below are its)
@@ -599,7 +673,9 @@ def main():
                 "frac_overlapped": ach_ov / HBM_PEAK_GBPS,
                 "frac_solo": ach_solo / HBM_PEAK_GBPS,
                 "frac_aggregate": ach_agg / HBM_PEAK_GBPS,
-                "device_copy_gbps": copy_gbps,   # torch d2d copy of 1 GiB (read + write bytes), same box, alone
+                "device_copy_gbps": max(copy_gbps, copy16_gbps),   # the box's best plain stream rate: 1 GiB device to device (read + write bytes), alone
+                "device_copy_gbps_torch": copy_gbps,             # torch's copy_
+                "device_copy_gbps_float4": copy16_gbps,          # hand-written 16-byte-per-lane copy (ai_bench_copy)
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "overlapped": {"launches": ov["launches"], "avg_launch_us": 1e3 * ov["ms"] / max(ov["launches"], 1),
@@ -612,7 +688,7 @@ def main():
             },
         }
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only: the other ranks would sit in the final barrier
-            out["cpu_baseline"] = cpu_baseline(with_50k=args.cpu_50k)
+            out["cpu_baseline"] = cpu_baseline(with_50k=False if args.no_cpu_50k else (True if args.cpu_50k else None))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -269,6 +269,13 @@ int ai_unique_points(ai_ctx* ctx, const double* xyz, int64_t n, int mem_kind, in
  */
 int ai_bench_spmv(ai_ctx* ctx, const ai_csr* csr, int32_t reps, double* avg_ms, double* bytes_per_launch);
 
+/*
+ * Timing hook for bench.py: the box's plain stream rate.  `reps` device-to-device copies of `bytes` bytes (16 bytes per lane per
+ * access, four accesses in flight per thread, every block its own contiguous range), timed with HIP events on the context's stream;
+ * *gbps = read + written bytes per second / 1e9.  What a roofline fraction of an HBM-bound kernel is quoted beside.
+ */
+int ai_bench_copy(ai_ctx* ctx, int64_t bytes, int32_t reps, double* gbps);
+
 #ifdef __cplusplus
 }
 #endif
