@@ -276,6 +276,36 @@ __device__ __forceinline__ double ai_hash_unit(uint32_t id) {
   return (double)(x >> 11) * (2.0 / 9007199254740992.0) - 1.0;
 }
 
+// THE RULE for memory that another stream of the call, or the host, rewrites while the call runs (pool tables and their ring of
+// versions, SegRec tables in pinned memory, per-slot check state, activity flags, Lanczos histories, step counters): no PLAIN load.
+// A plain load of a block-uniform address becomes a scalar load through the scalar cache, which is not coherent with another
+// stream's or the host's writes; round 3 lost one chunk in ~700 to exactly that (fk_check).  ai_ld_agent (device-written data) and
+// ai_ld_sys (host-written pinned data) are relaxed atomic loads: vector loads that bypass the non-coherent caches.
+// DESIGN.md section 6 lists the audited sites; grep for these two names to find them.
+template <typename T>
+__device__ __forceinline__ T ai_ld_agent(const T* p) {
+  return __hip_atomic_load(const_cast<T*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T>
+__device__ __forceinline__ T ai_ld_sys(const T* p) {
+  return __hip_atomic_load(const_cast<T*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+template <typename T>
+__device__ __forceinline__ void ai_st_agent(T* p, T v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// a record of NI 32-bit words (a multiple of 4 bytes, 4-byte aligned) from host-written pinned memory
+template <typename R>
+__device__ __forceinline__ R ai_ld_sys_record(const R* p) {
+  static_assert(sizeof(R) % 4 == 0, "record of 32-bit words");
+  R r;
+  int32_t* d = reinterpret_cast<int32_t*>(&r);
+  const int32_t* q = reinterpret_cast<const int32_t*>(p);
+#pragma unroll
+  for (int k = 0; k < (int)(sizeof(R) / 4); ++k) d[k] = ai_ld_sys(q + k);
+  return r;
+}
+
 // blockIdx -> task remap so that each XCD (blocks b, b+8, ... share one) works on one
 // contiguous eighth of the rows: its L2 then holds one slice of the gathered vector.
 __device__ __forceinline__ int ai_xcd_task(int bid, int nblk) {
