@@ -3,9 +3,9 @@
 The reference runs ``for sequence in tqdm(range(#chunks)): ncuts_chunk(...)`` serially
 (``pipeline/run_pipeline.py:160-179``); chunks are independent (each writes its own ``.pcd``,
 ``:194``), so they shard with NO data-path collective: one process per GPU, a static
-longest-processing-time assignment by chunk size, and one gather of the int32 label arrays to
-rank 0 at the end (a few hundred KB per chunk: RCCL over xGMI with the ``nccl`` backend, ``gloo``
-in CPU tests).  ``merge_chunks_unite_instances2`` stays serial on rank 0, as in the reference.
+longest-processing-time assignment by chunk size, and one ROOTED gather of the int32 label arrays to
+rank 0 per step (counts, then a direct send of each rank's arrays to the root: a few hundred KB per chunk, RCCL over xGMI
+with the ``nccl`` backend, ``gloo`` in CPU tests; the root parses on a helper thread).  ``merge_chunks_unite_instances2`` stays serial on rank 0, as in the reference.
 
 Inside one rank `run_chunks` is that loop for one GPU: two host threads (one `Context` each) take batches of
 chunks from one queue and push each batch through ONE batched call (`ncuts_labels_batch`: the connected segments of the
@@ -38,52 +38,90 @@ def lpt_assign(sizes, world_size: int):
     return [sorted(x) for x in out]
 
 
-def gather_labels(local: dict, device=None, force: bool = False):
-    """Gather ``{chunk_index: int32 label array}`` from every rank to rank 0.
+_parse_pool = None
 
-    Uses the default ``torch.distributed`` process group (``nccl`` = RCCL on the GPUs, ``gloo``
-    on CPU).  Two steps: all-gather of (count, total length) so every rank knows the padded
-    size, then an all-gather of one padded int32 buffer per rank.  Returns the merged dict on rank 0
-    and ``None`` elsewhere.  Without an initialised group (or with one rank, unless ``force``) it is
-    the identity.
-    """
-    import torch
-    import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
-        return dict(local)
-    world, rank = dist.get_world_size(), dist.get_rank()
-    if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+def _parser():
+    """One helper thread per process parses what the root has received (a step's 134 MB at 8 ranks is a few tens of
+    milliseconds of NumPy copies): the thread that issues the collectives goes straight on to the next step."""
+    global _parse_pool
+    if _parse_pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _parse_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="autoinst-gather")
+    return _parse_pool
+
+
+def _pack(local: dict):
     keys = sorted(local)
     lens = [int(local[k].shape[0]) for k in keys]
     # payload: [n_chunks, (chunk id, length) * n_chunks, labels...]
     head = np.array([len(keys)] + [v for kl in zip(keys, lens) for v in kl], dtype=np.int32)
     body = np.concatenate([np.asarray(local[k], dtype=np.int32) for k in keys]) if keys else np.zeros(0, np.int32)
-    payload = np.concatenate([head, body])
-    size = torch.tensor([payload.shape[0]], dtype=torch.int64, device=device)
-    sizes = [torch.zeros_like(size) for _ in range(world)]
-    dist.all_gather(sizes, size)
-    mx = int(max(int(s.item()) for s in sizes))
-    buf = torch.zeros(mx, dtype=torch.int32, device=device)
-    buf[: payload.shape[0]] = torch.from_numpy(payload).to(device)
-    # all-gather (the one collective every backend has) of a few hundred KB per rank; only rank 0
-    # keeps the result.  A rooted gather would save nothing measurable at this size.
-    recv = [torch.zeros_like(buf) for _ in range(world)]
-    dist.all_gather(recv, buf)
-    if rank != 0:
-        return None
-    merged = {}
-    for r in range(world):
-        a = recv[r].cpu().numpy()
-        nc = int(a[0])
-        off = 1 + 2 * nc
-        for c in range(nc):
-            k, ln = int(a[1 + 2 * c]), int(a[2 + 2 * c])
-            merged[k] = a[off: off + ln].copy()
-            off += ln
-    return merged
+    return np.concatenate([head, body])
 
+
+def _unpack(a: np.ndarray, merged: dict):
+    nc = int(a[0])
+    off = 1 + 2 * nc
+    for c in range(nc):
+        k, ln = int(a[1 + 2 * c]), int(a[2 + 2 * c])
+        merged[k] = a[off: off + ln].copy()
+        off += ln
+
+
+def gather_labels_async(local: dict, device=None, force: bool = False):
+    """Rooted gather of ``{chunk_index: int32 label array}`` to rank 0 (counts first, then a direct
+    send of every rank's arrays to the root -- on the GPUs one hop over xGMI with the ``nccl`` = RCCL backend, ``gloo`` in CPU
+    tests).  Two steps on the default process group: ``gather`` of the payload sizes to rank 0, then ONE grouped exchange: every
+    other rank sends its exact-size buffer, the root posts the matching receives (`batch_isend_irecv`); nothing is padded and no
+    rank but the root receives anything.  Must be called by every rank, by the same thread each time (collectives are ordered).
+
+    Returns a ``concurrent.futures.Future`` on rank 0 whose result is the merged dict (the copies off the device and the
+    parsing run on a helper thread, so the caller can issue the next step's exchange meanwhile) and ``None`` on the other
+    ranks.  Without an initialised group (or with one rank, unless ``force``) the future holds ``dict(local)``.
+    """
+    from concurrent.futures import Future
+
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
+        f = Future()
+        f.set_result(dict(local))
+        return f
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    payload = _pack(local)
+    size = torch.tensor([payload.shape[0]], dtype=torch.int64, device=device)
+    sizes = [torch.zeros_like(size) for _ in range(world)] if rank == 0 else None
+    dist.gather(size, gather_list=sizes, dst=0)
+    if rank != 0:
+        buf = torch.from_numpy(payload).to(device)
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, buf, 0)]):
+            w.wait()
+        return None
+    recv = {r: torch.empty(int(sizes[r].item()), dtype=torch.int32, device=device) for r in range(1, world)}
+    if recv:
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, recv[r], r) for r in sorted(recv)]):
+            w.wait()
+    if device.type == "cuda":
+        torch.cuda.current_stream(device).synchronize()   # the receives have landed before the helper thread reads them
+
+    def parse():
+        merged = {}
+        _unpack(payload, merged)
+        for r in sorted(recv):
+            _unpack(recv[r].cpu().numpy(), merged)
+        return merged
+
+    return _parser().submit(parse)
+
+
+def gather_labels(local: dict, device=None, force: bool = False):
+    """`gather_labels_async` and its result: the merged dict on rank 0, ``None`` elsewhere."""
+    f = gather_labels_async(local, device=device, force=force)
+    return None if f is None else f.result()
 
 
 def run_chunks(chunks, *, threads: int = 2, batch: int = 12, device: int | None = None, alpha=None, theta=None, gamma=None,

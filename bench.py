@@ -269,15 +269,31 @@ def dry_run(args, world, rank):
         dist.init_process_group("gloo")
     rng = np.random.default_rng(0)
     nchunks = world * args.in_flight * args.batch
-    sizes = np.exp(rng.uniform(np.log(3_000), np.log(30_000), nchunks)).astype(int).tolist()   # cfg3's chunk-size mix
-    mine = sharding.lpt_assign(sizes, world)[rank]
+    sizes = np.exp(rng.uniform(np.log(3_000), np.log(30_000), nchunks)).astype(int).tolist()   # cfg3's chunk-size mix: an UNEVEN deal
+    deal = sharding.lpt_assign(sizes, world)
+    mine = deal[rank]
+    loads = [sum(sharding.chunk_cost(sizes[c]) for c in d) for d in deal]
+    t_pack = t_gather = t_parse = 0.0
 
     def step():
+        nonlocal t_pack, t_gather, t_parse
+        t0 = time.perf_counter()
         local = {c: (np.arange(sizes[c], dtype=np.int32) % 7) for c in mine}
-        return sharding.gather_labels(local, device=torch.device("cpu")) if world > 1 else local
+        t1 = time.perf_counter()
+        if world == 1:
+            return local
+        fut = sharding.gather_labels_async(local, device=torch.device("cpu"))
+        t2 = time.perf_counter()
+        out = None if fut is None else fut.result()
+        t3 = time.perf_counter()
+        t_pack += t1 - t0
+        t_gather += t2 - t1
+        t_parse += t3 - t2
+        return out
 
     for _ in range(args.warmup):
         step()
+    t_pack = t_gather = t_parse = 0.0
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
@@ -292,11 +308,19 @@ def dry_run(args, world, rank):
         elapsed = float(t.item())
     if rank == 0:
         assert merged is not None and sorted(merged) == list(range(nchunks)) and all(merged[c].shape[0] == sizes[c] for c in merged)
+        mean_load = sum(loads) / world
         print(json.dumps({"metric": "dry run: chunk deal + label gather only (no compute)", "dry": True, "value": nchunks * args.steps / elapsed,
                           "unit": "chunks/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": "int32", "data": "synthetic", "rccl_ranks": world, "backend": "gloo" if world > 1 else "none",
-                          "config": {"workload": "label arrays of an uneven chunk list, LPT-dealt", "chunks_per_step": nchunks}}), flush=True)
+                          "config": {"workload": "label arrays of an uneven chunk list (3k-30k points, log-uniform), LPT-dealt", "chunks_per_step": nchunks},
+                          # what the deal and the root cost, in numbers: the slowest rank's share of the cost model over the mean share
+                          # (1.0 = perfectly even: the step time of a real run is bound by it), and the root's per-step times
+                          "lpt": {"points_per_rank": [sum(sizes[c] for c in d) for d in deal], "chunks_per_rank": [len(d) for d in deal],
+                                  "cost_max_over_mean": max(loads) / mean_load, "predicted_efficiency_from_imbalance": mean_load / max(loads)},
+                          "root_ms_per_step": {"pack": 1e3 * t_pack / args.steps, "exchange_calls": 1e3 * t_gather / args.steps,
+                                               "wait_for_parse": 1e3 * t_parse / args.steps},
+                          "label_bytes_per_step": int(4 * sum(sizes))}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -479,7 +503,7 @@ def main():
         for s_ in range(nsteps):
             for k in range(M):
                 (uploads if kw.get("from_host") else work).put((s_, k, kw))
-        last = None
+        last, pending = None, None
         for s_ in range(nsteps):
             with cv:
                 cv.wait_for(lambda: all((s_, k) in results for k in range(M)))
@@ -493,8 +517,17 @@ def main():
                         os._exit(1)
                     raise r
             local = {my_chunks[k * B + b]: res[k][0][b] for k in range(M) for b in range(B)}
-            merged = sharding.gather_labels(local, device=dev) if world > 1 else local
-            last = (res, merged)
+            if world > 1:
+                # rooted exchange issued by this thread; the root parses step s on a helper thread while step s + 1 computes
+                fut = sharding.gather_labels_async(local, device=dev)
+                if pending is not None:
+                    pending.result()
+                pending = fut
+                last = (res, None)
+            else:
+                last = (res, local)
+        if world > 1:
+            last = (last[0], pending.result() if pending is not None else None)   # inside the timed region: the last step's labels are on the root
         return last
 
     def barrier():
