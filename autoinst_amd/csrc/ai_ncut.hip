@@ -48,6 +48,7 @@ namespace {
 #include "ai_flow.inc"
 }  // namespace
 
+#ifdef AI_WITH_LOCKSTEP   // the level-synchronous recursion driver: only in the test-only build libautoinst_hip_lockstep.so (Makefile: make lockstep)
 // ----------------------------------------------------------------------------- recursion driver + C ABI
 static int ncut_lockstep(ai_ctx* ctx, const ai_csr* csr, int nchunks, const int64_t* off, const int64_t* n_orig, double T, double split_lim,
                      const ai_ncut_opts* opts, int32_t* const* labels_out, int32_t* n_groups, ai_ncut_stats* stats_out, double t0) {
@@ -310,12 +311,23 @@ static int ncut_lockstep(ai_ctx* ctx, const ai_csr* csr, int nchunks, const int6
   }
   return AI_OK;
 }
+#endif  // AI_WITH_LOCKSTEP
 
-// AI_NCUT_LOCKSTEP=1 selects the level-synchronous driver (kept for A/B measurements); the default is the asynchronous frontier
+// The shipped library has ONE recursion driver, the asynchronous frontier (ai_flow.inc).  The level-synchronous driver of rounds
+// 1-2 (ncut_lockstep above: the same per-segment arithmetic, one recursion depth at a time) is compiled only into the test-only
+// build libautoinst_hip_lockstep.so (-DAI_WITH_LOCKSTEP), where AI_NCUT_LOCKSTEP=1 selects it: tests/test_gpu_parity.py and
+// tests/tools/fuzz_drivers.py load that build to check that both drivers give identical labels.
 static int ncut_impl(ai_ctx* ctx, const ai_csr* csr, int nchunks, const int64_t* off, const int64_t* n_orig, double T, double split_lim,
                      const ai_ncut_opts* opts, int32_t* const* labels_out, int32_t* n_groups, ai_ncut_stats* stats_out, double t0) {
   static const int lockstep = getenv("AI_NCUT_LOCKSTEP") ? atoi(getenv("AI_NCUT_LOCKSTEP")) : 0;
+#ifdef AI_WITH_LOCKSTEP
   if (lockstep) return ncut_lockstep(ctx, csr, nchunks, off, n_orig, T, split_lim, opts, labels_out, n_groups, stats_out, t0);
+#else
+  if (lockstep) {
+    ai_set_error("AI_NCUT_LOCKSTEP=1: this build has no level-synchronous driver (load libautoinst_hip_lockstep.so: make -C autoinst_amd/csrc lockstep)");
+    return AI_ERR_BAD_ARG;
+  }
+#endif
   return ncut_flow(ctx, csr, nchunks, off, n_orig, T, split_lim, opts, labels_out, n_groups, stats_out, t0);
 }
 

@@ -56,6 +56,8 @@ if __name__ == "__main__":
     for name, (lock, batched) in runs.items():
         path = os.path.join(tmp, name + ".npz")
         env = dict(os.environ, AI_NCUT_LOCKSTEP=lock)
+        if lock == "1":   # the level-synchronous driver lives in the test-only build (make -C autoinst_amd/csrc lockstep)
+            env["AUTOINST_HIP_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "autoinst_amd", "libautoinst_hip_lockstep.so")
         subprocess.run([sys.executable, os.path.abspath(__file__), "--worker", str(nchunks), str(seed), path, batched], check=True, env=env, timeout=1500)
         out[name] = np.load(path)
     ref = out["lockstep"]
