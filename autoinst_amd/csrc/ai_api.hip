@@ -3,6 +3,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <stdlib.h>
+#include <hip/hip_ext.h>
 #include "ai_common.h"
 
 static thread_local char g_err[1024] = "";
@@ -153,6 +155,8 @@ extern "C" int ai_ctx_create(int device, ai_ctx** out) {
   auto build = [&]() -> int {
     AI_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (int i = 0; i < 8; ++i) AI_HIP(hipEventCreate(&c->ev[i]));
+    // (confining this stream and the wave stream to 32 / 64 / 128 CUs with hipExtStreamCreateWithCUMask was measured in round 4:
+    // 105 / 91 / 96 chunks/s against 119 without a mask -- the checks and waves are on the critical path of every solve)
     AI_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     for (int i = 0; i < AI_CHECK_DEPTH; ++i) {
       AI_HIP(hipEventCreateWithFlags(&c->chk_ev[i], hipEventDisableTiming));

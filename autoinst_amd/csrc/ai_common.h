@@ -294,7 +294,21 @@ template <typename T>
 __device__ __forceinline__ void ai_st_agent(T* p, T v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// a record of NI 32-bit words (a multiple of 4 bytes, 4-byte aligned) from host-written pinned memory
+// a record of 32-bit words from host-written pinned memory, for the whole block: thread k loads word k ONCE (a system-scope load
+// crosses the bus: 256 threads loading the same 16 words each made fk_expand_pool ten times longer), LDS hands it round
+template <typename R>
+__device__ __forceinline__ R ai_ld_sys_record_block(const R* p, int32_t* sm /* sizeof(R) / 4 words of LDS */) {
+  static_assert(sizeof(R) % 4 == 0, "record of 32-bit words");
+  constexpr int NW = (int)(sizeof(R) / 4);
+  if ((int)threadIdx.x < NW) sm[threadIdx.x] = ai_ld_sys(reinterpret_cast<const int32_t*>(p) + threadIdx.x);
+  __syncthreads();
+  R r;
+  int32_t* d = reinterpret_cast<int32_t*>(&r);
+#pragma unroll
+  for (int k = 0; k < NW; ++k) d[k] = sm[k];
+  return r;
+}
+// the same for one thread (tables copied element-wise: each element is loaded by exactly one thread)
 template <typename R>
 __device__ __forceinline__ R ai_ld_sys_record(const R* p) {
   static_assert(sizeof(R) % 4 == 0, "record of 32-bit words");
