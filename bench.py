@@ -54,7 +54,7 @@ N_POINTS = 200_000
 CFG = dict(alpha=1.0, theta=0.5, gamma=0.0, T=0.03)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 CPU_200K_CACHE = os.path.join(ROOT, "profiles", "r02_cpu_oracle_200k.json")
-PMC_TRAFFIC = [os.path.join(ROOT, "profiles", "r03_pmc_traffic.json"), os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")]
+PMC_TRAFFIC = [os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic.json") for r in (4, 3, 2)]   # newest first
 
 
 def spmv_bytes(rows: int, nnz: int, launches: int) -> float:
