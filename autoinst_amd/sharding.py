@@ -72,9 +72,9 @@ def _unpack(a: np.ndarray, merged: dict):
 def gather_labels_async(local: dict, device=None, force: bool = False):
     """Rooted gather of ``{chunk_index: int32 label array}`` to rank 0 (counts first, then a direct
     send of every rank's arrays to the root -- on the GPUs one hop over xGMI with the ``nccl`` = RCCL backend, ``gloo`` in CPU
-    tests).  Two steps on the default process group: ``gather`` of the payload sizes to rank 0, then ONE grouped exchange: every
-    other rank sends its exact-size buffer, the root posts the matching receives (`batch_isend_irecv`); nothing is padded and no
-    rank but the root receives anything.  Must be called by every rank, by the same thread each time (collectives are ordered).
+    tests).  Two collectives on the default process group: an ``all_reduce(MAX)`` of the payload length (8 bytes), then ONE rooted
+    ``gather`` of the payloads padded to that length -- no rank but the root receives anything, and chunks of one size need no
+    padding.  Must be called by every rank, by the same thread each time (collectives are ordered).
 
     Returns a ``concurrent.futures.Future`` on rank 0 whose result is the merged dict (the copies off the device and the
     parsing run on a helper thread, so the caller can issue the next step's exchange meanwhile) and ``None`` on the other
@@ -93,20 +93,21 @@ def gather_labels_async(local: dict, device=None, force: bool = False):
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     payload = _pack(local)
+    # (i) the longest payload, known to every rank (8 bytes); (ii) ONE rooted gather of the payloads, padded to that length: only
+    # the root receives.  `gather` is the collective RCCL / NCCL implement as a group of direct sends to the root, which is the
+    # exchange SURVEY section 5 specifies; chunks of one size (the bench) need no padding at all.
     size = torch.tensor([payload.shape[0]], dtype=torch.int64, device=device)
-    sizes = [torch.zeros_like(size) for _ in range(world)] if rank == 0 else None
-    dist.gather(size, gather_list=sizes, dst=0)
+    dist.all_reduce(size, op=dist.ReduceOp.MAX)
+    mx = int(size.item())
+    buf = torch.zeros(mx, dtype=torch.int32, device=device)
+    buf[: payload.shape[0]] = torch.from_numpy(payload).to(device)
+    recv = [torch.empty(mx, dtype=torch.int32, device=device) for _ in range(world)] if rank == 0 else None
+    dist.gather(buf, gather_list=recv, dst=0)
     if rank != 0:
-        buf = torch.from_numpy(payload).to(device)
-        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, buf, 0)]):
-            w.wait()
         return None
-    recv = {r: torch.empty(int(sizes[r].item()), dtype=torch.int32, device=device) for r in range(1, world)}
-    if recv:
-        for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, recv[r], r) for r in sorted(recv)]):
-            w.wait()
     if device.type == "cuda":
-        torch.cuda.current_stream(device).synchronize()   # the receives have landed before the helper thread reads them
+        torch.cuda.current_stream(device).synchronize()   # the gather has landed before the helper thread reads it
+    recv = {r: recv[r] for r in range(1, world)}
 
     def parse():
         merged = {}
