@@ -206,7 +206,8 @@ struct DevBuf {
 // out[0..n] = exclusive prefix sums of in[0..n-1]; out[n] = total.  in may alias out.
 // tmp must hold ai_scan_tmp_elems(n) int32.
 size_t ai_scan_tmp_elems(int64_t n);
-int ai_exclusive_scan_i32(hipStream_t stream, const int32_t* in, int32_t* out, int64_t n, int32_t* tmp);
+// total_out (may be null): pinned host address that also receives the total
+int ai_exclusive_scan_i32(hipStream_t stream, const int32_t* in, int32_t* out, int64_t n, int32_t* tmp, int32_t* total_out = nullptr);
 
 // ----------------------------------------------------------------------------- device helpers
 #ifdef __HIPCC__
