@@ -361,6 +361,14 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     if world > 1:
+        # one rank per GPU on one node: keep the rank's threads (two feeding threads, their helper threads, the gather's parser) and
+        # the pinned memory they first-touch on the CPUs of the GPU's NUMA node
+        try:
+            _node, _near, _note = gpu_numa_cpus(torch, local_rank)
+            if _near and len(_near) >= 8:
+                os.sched_setaffinity(0, _near)
+        except OSError:
+            pass
         import datetime
         # a rank that dies leaves the others in a collective: the timeout turns that into a failure
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=600))
