@@ -36,8 +36,10 @@ def test_soak_two_threads_thin_tail_chunks():
                 if first is None:
                     first = cur
                 else:
-                    assert cur[2:] == first[2:], (w, reps, cur[2:], first[2:])
-                    assert cur[1] == first[1] and all(np.array_equal(a, b) for a, b in zip(cur[0], first[0])), (w, reps)
+                    lab_diff = [int((np.asarray(a) != np.asarray(b)).sum()) for a, b in zip(cur[0], first[0])]
+                    assert cur[2:] == first[2:] and cur[1] == first[1] and not any(lab_diff), (
+                        f"thread {w}, repeat {reps}: counters {cur[2:]} vs first {first[2:]}; groups {cur[1]} vs {first[1]}; "
+                        f"labels that differ per chunk {lab_diff}")
                 reps += 1
             results[w] = reps
             ctx.close()
@@ -50,6 +52,15 @@ def test_soak_two_threads_thin_tail_chunks():
     for t in ts:
         t.join()
     if errors:
+        # keep the evidence where a GPU-box run merges it back (gpurun_out/), whatever the test runner prints
+        try:
+            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(root, "gpurun_out", "soak_failure.txt"), "a") as f:
+                for e in errors:
+                    f.write(f"{time.strftime('%Y-%m-%d %H:%M:%S')} {type(e).__name__}: {e}\n")
+        except OSError:
+            pass
         raise errors[0]
     assert all(r and r >= 3 for r in results), results
     print(f"soak: {results} repeats of 4-chunk calls in {budget:.0f} s, every one equal to its first")
