@@ -151,6 +151,7 @@ typedef struct {
   double ms_sweep;         /* level-synchronous driver only: device time in min/max + bin + sweep */
   double ms_rebuild;       /* level-synchronous driver only: device time in CC + partition + CSR rebuild */
   double max_resid;        /* largest accepted Ritz residual */
+  int64_t restarted_solves; /* solves repeated because the Ritz pair of a 'converged' segment failed the true-residual test ||M v - theta v|| <= 1e-5 ||v|| (0 in a healthy run; the repeat is bit-identical to an undisturbed solve) */
 } ai_ncut_stats;
 
 /*

@@ -328,6 +328,38 @@ def test_hundreds_of_chunks_in_one_call_and_children_that_wait_for_a_slot(api, m
 
 
 @pytest.mark.gpu
+def test_a_spoiled_ritz_pair_is_caught_by_the_true_residual_and_solved_again(api, monkeypatch):
+    """Every harvested Ritz pair is tested against the segment's own operator (fk_resid: ||M v - theta v|| <= 1e-5 ||v||) before it
+    is cut.  AI_FLOW_INJECT=k spoils the Ritz coefficients of the k-th harvested segment of a call, the way a check that froze
+    a segment on bad data would: the segment is solved again (same graph, same start vector), the labels are those of the
+    undisturbed call, and stats['restarted_solves'] says it happened.  A healthy call restarts nothing."""
+    from autoinst_amd import synth
+    ch = synth.synthetic_chunk(30000, 21, tarl=True)
+    g = api.build_affinity(ch["points"], ch["tarl"], alpha=1.0, theta=0.5, gamma=0.0)
+    lab0, ng0, st0 = api.ncuts_labels(g, g.n, 0.03)
+    assert st0["restarted_solves"] == 0 and st0["unconverged"] == 0
+    assert st0["lanczos_solves"] > 12
+    for k in (0, 1, 5, 12):
+        monkeypatch.setenv("AI_FLOW_INJECT", str(k))
+        lab, ng, st = api.ncuts_labels(g, g.n, 0.03)
+        monkeypatch.delenv("AI_FLOW_INJECT")
+        assert st["restarted_solves"] == 1, (k, st)
+        assert ng == ng0 and np.array_equal(lab, lab0), k
+        assert st["lanczos_solves"] == st0["lanczos_solves"] and st["unconverged"] == 0
+    # in a batched call too (the spoiled segment belongs to one of several chunks)
+    chunks = [synth.synthetic_chunk(n, 40 + i, tarl=False) for i, n in enumerate((9000, 14000, 5000))]
+    gs = [api.build_affinity(c["points"], None, alpha=1.0, theta=0.0, gamma=0.0) for c in chunks]
+    labs0, ngs0, stb0 = api.ncuts_labels_batch(gs, None, 0.05)
+    monkeypatch.setenv("AI_FLOW_INJECT", "4")
+    labs1, ngs1, stb1 = api.ncuts_labels_batch(gs, None, 0.05)
+    monkeypatch.delenv("AI_FLOW_INJECT")
+    assert stb0["restarted_solves"] == 0 and stb1["restarted_solves"] == 1
+    assert ngs1 == ngs0 and all(np.array_equal(a, b) for a, b in zip(labs1, labs0))
+    for x in gs + [g]:
+        x.free()
+
+
+@pytest.mark.gpu
 def test_level_synchronous_driver_gives_the_same_labels(tmp_path):
     """The level-synchronous driver of rounds 1-2 (test-only build libautoinst_hip_lockstep.so, AI_NCUT_LOCKSTEP=1) and the
     asynchronous frontier of the shipped library give identical labels: same solver arithmetic per segment, same sweep, same

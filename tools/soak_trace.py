@@ -39,6 +39,8 @@ for r in range(R):
         if l.startswith("[anom]"):
             print(r, l, flush=True)
     lines = sorted(l for l in raw if l.startswith("[seg]"))
+    if r % 300 == 299:
+        print(f"progress: {r + 1} repeats, {events} events", flush=True)   # (a GPU-box run that stays silent for minutes is taken to be hung)
     if first is None:
         first = (lines, [np.asarray(l).copy() for l in labs])
         print("segments:", len(lines), flush=True)
