@@ -428,6 +428,18 @@ __device__ __forceinline__ double aw_group8_sum(double v) {
   return v;
 }
 
+#ifndef AW_GRP
+#define AW_GRP 2      // entry pairs whose LDS reads are in flight together (k_weights_lanes; 1 / 2 / 4: 437 / 425 / 453 us at 96-d, 1499 / 1409 / 1416 us at 96-d + 384-d)
+#endif
+#ifndef AW_PACK
+#define AW_PACK 2     // staged offsets per register
+#endif
+#ifdef AW_PHASES
+__device__ unsigned long long g_aw_phase[8];
+#define AW_STAMP(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&g_aw_phase[k], t_ - aw_t); aw_t = t_; } } while (0)
+#else
+#define AW_STAMP(k) do { } while (0)
+#endif
 #define AW_ECAP 2048   // entries of a tile whose hash slot is remembered (more: fallback)
 template <int AW_MAXD, int ACC>
 __global__ __launch_bounds__(AI_BLOCK, 3) void k_weights_lanes(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
@@ -449,6 +461,9 @@ __global__ __launch_bounds__(AI_BLOCK, 3) void k_weights_lanes(const int32_t* __
   __shared__ int32_t srow[AW_ROWS + 1];
   __shared__ int32_t wcnt[AI_BLOCK / 64];
   __shared__ int32_t s_over;
+#ifdef AW_PHASES
+  unsigned long long aw_t = wall_clock64();
+#endif
   const int nblk = gridDim.x;
   const int64_t r0 = (int64_t)ai_xcd_task(blockIdx.x, nblk) * AW_ROWS;
   if (r0 >= n) return;
@@ -484,6 +499,7 @@ __global__ __launch_bounds__(AI_BLOCK, 3) void k_weights_lanes(const int32_t* __
     }
   }
   __syncthreads();
+  AW_STAMP(0);  // hash build
   // ---- number the occupied slots (ballot + prefix over the four waves: no counter to contend for)
   int nd = 0;
   {
@@ -534,6 +550,7 @@ __global__ __launch_bounds__(AI_BLOCK, 3) void k_weights_lanes(const int32_t* __
   __syncthreads();
   for (int i = tid; i < e1 - e0; i += AI_BLOCK) eslot[i] = cidx[eslot[i]];  // hash slot -> staged position
   __syncthreads();
+  AW_STAMP(1);  // numbering, slot -> position
   const int l = tid & 15, g = tid >> 4;  // lane in the row group, row of the tile
   const int h = l >> 3, m = l & 7;       // entry slot of the pair in flight, lane of the 8 that share an entry
   const bool rlive = g < nrows;
@@ -547,27 +564,48 @@ __global__ __launch_bounds__(AI_BLOCK, 3) void k_weights_lanes(const int32_t* __
     // staged position of entry slot 2 * it + h of this row, two per register; a slot without an entry points at the row
     // itself (distance 0: adds nothing)
     // (kept as the BYTE offset of this lane's two dimensions in the slab buffer)
-    uint32_t cj2[ACC];
+    // (two 16-bit offsets per register: the 16 registers this saves are what the grouped reads below need).  The 32 reads of
+    // `eslot` are unconditional (a slot without an entry reads position 0 and discards it), so that they are issued together.
+    static_assert(AW_MAXD * AW_SLAB * 8 <= 65536, "a staged byte offset fits 16 bits");
+    uint32_t cj2[ACC / AW_PACK];
+    {
+      uint32_t sl_[ACC];
 #pragma unroll
-    for (int it = 0; it < ACC; ++it) {
-      uint32_t c = ci;
-      if (it < rounds) {
+      for (int it = 0; it < ACC; ++it) {
         const int32_t e = p0 + base + 2 * it + h;
-        if (e < p1) c = eslot[e - e0];
+        sl_[it] = eslot[(it < rounds && e < p1) ? e - e0 : 0];
       }
-      cj2[it] = c * (AW_SLAB * 8) + 16 * m;
+#pragma unroll
+      for (int it = 0; it < ACC; ++it) {
+        const int32_t e = p0 + base + 2 * it + h;
+        const uint32_t c = (it < rounds && e < p1) ? sl_[it] : ci;
+        const uint32_t off = c * (AW_SLAB * 8) + 16 * m;
+        if (AW_PACK == 1) cj2[it] = off;
+        else if ((it & 1) == 0) cj2[it >> 1] = off;
+        else cj2[it >> 1] |= off << 16;
+      }
     }
+    AW_STAMP(2);  // row set-up, offsets of the round
     double acc[ACC];
     // one feature block: squared distances of the round's entries, finished sums handed to lane (it & 7) of the 8
     auto run = [&](const double* __restrict__ f, int64_t dim, double (&fin)[EPT]) {
       // one slab of the tile's distinct rows straight into LDS (global_load_lds_dwordx4: 16 bytes per lane, a wave's 64
       // lanes fill 1 KB = 8 staged rows; no staging registers): piece p = (row p >> 3, dimensions 2 (p & 7), +1)
+      // where this lane's pieces start in slab 0, in 16-byte units (n * dim < 2^33, checked by the host), formed once per
+      // feature block: read from `corig` inside `stage`, each of the 8 DMAs of a slab waited for its own LDS round trip
+      // (the compiler cannot move a read of LDS across a DMA that writes LDS)
+      uint32_t roff[AW_STAGE / 2];
+#pragma unroll
+      for (int i = 0; i < AW_STAGE / 2; ++i) {
+        const int p = tid + AI_BLOCK * i;
+        const int c = min(p >> 3, nd - 1);
+        roff[i] = (uint32_t)(((uint64_t)(uint32_t)corig[c] * (uint64_t)dim) >> 1) + (uint32_t)(p & 7);
+      }
       auto stage = [&](int sl) {
+        const char* fs = reinterpret_cast<const char*>(f + sl * AW_SLAB);
 #pragma unroll
         for (int i = 0; i < AW_STAGE / 2; ++i) {
-          const int p = tid + AI_BLOCK * i;
-          const int c = min(p >> 3, nd - 1);
-          const double* src = f + (int64_t)corig[c] * dim + sl * AW_SLAB + 2 * (p & 7);
+          const char* src = fs + ((uint64_t)roff[i] << 4);
           double* dst = xs + 2 * ((tid & ~63) + AI_BLOCK * i);  // wave-uniform; lane l lands at dst + 2 l
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                            (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -583,19 +621,31 @@ __global__ __launch_bounds__(AI_BLOCK, 3) void k_weights_lanes(const int32_t* __
         __syncthreads();
         if (rlive) {
           const double2 fi = *reinterpret_cast<const double2*>(&xs[ci * AW_SLAB + 2 * m]);
+          // entry pairs in groups of AW_GRP: the group's LDS reads are issued together and their latencies overlap.  (With
+          // the block-uniform guard `it < rounds` around every single pair -- rounds 1-3 -- the compiler emitted, per pair,
+          // read / s_waitcnt lgkmcnt(0) / four DP instructions / scalar branch: one LDS round trip of ~130 cycles exposed per
+          // pair, 25 pairs x 6 slabs per wave.)  A slot past the last pair points at the row itself: d = +0, fma(0, 0, acc)
+          // = acc exactly, so the pairs a group adds beyond `rounds` change no bit.
 #pragma unroll
-          for (int it = 0; it < ACC; ++it) {
-            if (it < rounds) {
-              const uint32_t off = cj2[it];
-              const double2 b = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(xs) + off);
-              const double d0 = fi.x - b.x;
-              acc[it] = fma(d0, d0, acc[it]);
-              const double d1 = fi.y - b.y;
-              acc[it] = fma(d1, d1, acc[it]);
+          for (int g0 = 0; g0 < ACC; g0 += AW_GRP) {
+            if (g0 < rounds) {
+              double2 b[AW_GRP];
+#pragma unroll
+              for (int u = 0; u < AW_GRP; ++u)
+                b[u] = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(xs) +
+                                                         (AW_PACK == 1 ? cj2[g0 + u] : ((g0 + u) & 1) ? (cj2[(g0 + u) >> 1] >> 16) : (cj2[(g0 + u) >> 1] & 0xFFFFu)));
+#pragma unroll
+              for (int u = 0; u < AW_GRP; ++u) {
+                const double d0 = fi.x - b[u].x;
+                acc[g0 + u] = fma(d0, d0, acc[g0 + u]);
+                const double d1 = fi.y - b[u].y;
+                acc[g0 + u] = fma(d1, d1, acc[g0 + u]);
+              }
             }
           }
         }
       }
+      AW_STAMP(3);  // slabs
 #pragma unroll
       for (int it = 0; it < ACC; ++it) {
         const double tot = aw_group8_sum(acc[it]);
@@ -607,6 +657,7 @@ __global__ __launch_bounds__(AI_BLOCK, 3) void k_weights_lanes(const int32_t* __
     for (int k = 0; k < EPT; ++k) t2[k] = g2[k] = 0.0;
     if (use_t) run(tarl, tdim, t2);
     if (use_d) run(dino, ddim, g2);
+    AW_STAMP(4);  // reductions over the 8 lanes
     // lane m of entry slot h finishes the entries 2 * (8 k + m) + h of the round
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
@@ -617,6 +668,7 @@ __global__ __launch_bounds__(AI_BLOCK, 3) void k_weights_lanes(const int32_t* __
         val[e] = aw_weight(val[e], t, g2[k], use_t, use_d, alpha, theta, gamma);
       }
     }
+    AW_STAMP(5);  // weights
   }
 }
 
@@ -638,6 +690,17 @@ static int upload_if_host(const double* src, size_t count, int mem_kind, DevBuf<
   *dev = own.p;
   return AI_OK;
 }
+
+#ifdef AW_PHASES
+extern "C" int ai_debug_aw_phases(unsigned long long* out, int reset) {
+  AI_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_aw_phase), sizeof(unsigned long long) * 8));
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    AI_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_aw_phase), z, sizeof(z)));
+  }
+  return AI_OK;
+}
+#endif
 
 extern "C" int ai_affinity_build(ai_ctx* ctx, const double* xyz, int64_t n, const double* tarl, int32_t tarl_dim,
                                  const double* dino, int32_t dino_dim, double alpha, double theta, double gamma,
@@ -851,7 +914,8 @@ extern "C" int ai_affinity_build_sam(ai_ctx* ctx, const double* xyz, int64_t n, 
     const unsigned gw = (unsigned)((n + (AI_BLOCK / 64) - 1) / (AI_BLOCK / 64));
     const bool has_t = d_tarl != nullptr, has_d = d_dino != nullptr;
     static const int force_rowwise = getenv("AI_WEIGHTS_ROWWISE") ? atoi(getenv("AI_WEIGHTS_ROWWISE")) : 0;
-    const bool tiled = !force_rowwise && (has_t || has_d) && d_sam == nullptr && (!has_t || tarl_dim % AW_SLAB == 0) && (!has_d || dino_dim % AW_SLAB == 0);
+    const bool tiled = !force_rowwise && (has_t || has_d) && d_sam == nullptr && (!has_t || tarl_dim % AW_SLAB == 0) && (!has_d || dino_dim % AW_SLAB == 0) &&
+                       (uint64_t)n * (uint64_t)std::max(has_t ? tarl_dim : 0, has_d ? dino_dim : 0) < ((uint64_t)1 << 33);  // staging offsets: 32 bits of 16-byte units
     if (tiled) {
       // LDS-tiled: every distinct neighbour's feature row is read once per 16-row tile
       hipLaunchKernelGGL((k_weights_lanes<256, 32>), dim3((unsigned)((n + 15) / 16)), dim3(AI_BLOCK), 0, st, (const int32_t*)A->rowptr,
