@@ -346,6 +346,13 @@ def test_a_spoiled_ritz_pair_is_caught_by_the_true_residual_and_solved_again(api
         assert st["restarted_solves"] == 1, (k, st)
         assert ng == ng0 and np.array_equal(lab, lab0), k
         assert st["lanczos_solves"] == st0["lanczos_solves"] and st["unconverged"] == 0
+    # a limit below every residual sends EVERY segment back once; the repeat must reproduce the residual bit for bit to be accepted
+    # (three different residuals end the call with an error): every solve of the chunk is shown to be reproducible inside one call
+    monkeypatch.setenv("AI_FLOW_TRUE_LIMIT", "1e-300")
+    lab, ng, st = api.ncuts_labels(g, g.n, 0.03)
+    monkeypatch.delenv("AI_FLOW_TRUE_LIMIT")
+    assert ng == ng0 and np.array_equal(lab, lab0)
+    assert st["restarted_solves"] >= 0.9 * st0["lanczos_solves"] - 2 and st["lanczos_solves"] == st0["lanczos_solves"], (st, st0)
     # in a batched call too (the spoiled segment belongs to one of several chunks)
     chunks = [synth.synthetic_chunk(n, 40 + i, tarl=False) for i, n in enumerate((9000, 14000, 5000))]
     gs = [api.build_affinity(c["points"], None, alpha=1.0, theta=0.0, gamma=0.0) for c in chunks]
