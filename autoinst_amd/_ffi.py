@@ -38,7 +38,7 @@ class NcutStats(C.Structure):
         ("unconverged", C.c_int64), ("n_groups", C.c_int64),
         ("ms_total", C.c_double), ("ms_eigen", C.c_double), ("ms_spmv", C.c_double),
         ("ms_sweep", C.c_double), ("ms_rebuild", C.c_double), ("max_resid", C.c_double),
-        ("restarted_solves", C.c_int64),
+        ("restarted_solves", C.c_int64), ("hist_retries", C.c_int64),
     ]
 
     def as_dict(self):

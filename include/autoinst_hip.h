@@ -156,6 +156,8 @@ typedef struct {
                                the same vector and is bit-identical to an undisturbed solve.  A repeat that arrives at the same
                                residual bit for bit is accepted (dense graphs with clustered top eigenvalues: Lanczos without
                                reorthogonalisation gives 3e-7 there), so the labels never depend on the test */
+  int64_t hist_retries;     /* waves whose packed Lanczos histories (device -> pinned host memory) failed their header check (size of T,
+                               integer checksum) and were packed again; 0 in a healthy run, labels do not depend on it */
 } ai_ncut_stats;
 
 /*

@@ -353,6 +353,15 @@ def test_a_spoiled_ritz_pair_is_caught_by_the_true_residual_and_solved_again(api
     monkeypatch.delenv("AI_FLOW_TRUE_LIMIT")
     assert ng == ng0 and np.array_equal(lab, lab0)
     assert st["restarted_solves"] >= 0.9 * st0["lanczos_solves"] - 2 and st["lanczos_solves"] == st0["lanczos_solves"], (st, st0)
+    # the packed histories of a wave carry the device's size of T and an integer checksum per row; AI_FLOW_INJECT_HIST=k makes the host
+    # reject the rows of the wave that holds the k-th harvested segment once: they are packed again, nothing else changes
+    for k in (0, 7):
+        monkeypatch.setenv("AI_FLOW_INJECT_HIST", str(k))
+        lab, ng, st = api.ncuts_labels(g, g.n, 0.03)
+        monkeypatch.delenv("AI_FLOW_INJECT_HIST")
+        assert st["hist_retries"] == 1 and st["restarted_solves"] == 0, (k, st)
+        assert ng == ng0 and np.array_equal(lab, lab0), k
+    assert st0["hist_retries"] == 0
     # in a batched call too (the spoiled segment belongs to one of several chunks)
     chunks = [synth.synthetic_chunk(n, 40 + i, tarl=False) for i, n in enumerate((9000, 14000, 5000))]
     gs = [api.build_affinity(c["points"], None, alpha=1.0, theta=0.0, gamma=0.0) for c in chunks]

@@ -53,6 +53,9 @@ def test_soak_two_threads_thin_tail_chunks():
                 labs, ngs, st = api.ncuts_labels_batch(graphs, None, 0.03)
                 for g in graphs:
                     g.free()
+                if st["hist_retries"]:
+                    # a packed history row failed its header check and the wave's rows were packed again
+                    note(logfile, f"thread {w}, repeat {reps}: {st['hist_retries']} wave(s) asked for their history rows again")
                 if st["restarted_solves"]:
                     # a Ritz pair failed the true-residual test and its segment was solved again: the labels must not show it
                     restarts[w] += st["restarted_solves"]
