@@ -1,5 +1,5 @@
 """Where a block of k_weights_lanes spends its time (device clock, wave 0 of every block), from a build with -DAW_PHASES:
-    AUTOINST_HIP_LIB=autoinst_amd/ab_ph.so python tools/probe_aw_phases.py
+    make -C autoinst_amd/csrc phases && AUTOINST_HIP_LIB=autoinst_amd/libautoinst_hip_awphases.so python tools/probe_aw_phases.py
 """
 import ctypes as C, os, sys
 import numpy as np, torch
