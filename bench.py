@@ -421,6 +421,8 @@ def main():
         stage_blocks = [torch.empty(B * (np_ + nf_), dtype=torch.float64, device=dev) for _ in range(K + 1)]
         views = lambda d: [(d[b * np_:(b + 1) * np_].view(shp_p), d[B * np_ + b * nf_:B * np_ + (b + 1) * nf_].view(shp_f)) for b in range(B)]
 
+    guard_counts = {"restarted_solves": 0, "hist_retries": 0, "calls": 0}   # (int += under the GIL)
+
     def one_batch(k, profile=False, only_first=False, from_host=False, w=None, staged=None):
         # batch k of the rank's M batches, run by host thread w on that thread's context
         ctx = ctxs[k % K if w is None else w]
@@ -441,6 +443,11 @@ def main():
             nnz = graphs[0].nnz
             for g in graphs:
                 g.free()
+        # the library's two self-checks (0 in a healthy run; labels do not depend on them): Ritz pairs that failed the true-residual test
+        # and were solved again, waves whose packed histories failed their header check and were packed again -- over every call of the run
+        guard_counts["restarted_solves"] += int(st.get("restarted_solves", 0))
+        guard_counts["hist_retries"] += int(st.get("hist_retries", 0))
+        guard_counts["calls"] += 1
         return labs, ngs, st, nnz
 
     import queue
@@ -703,6 +710,7 @@ def main():
             "lanczos_steps": int(st["lanczos_steps"]),
             "groups": int(ng),
             "unconverged": int(st["unconverged"]),
+            "self_checks": dict(guard_counts),   # over every library call of this run (warm-up, timed, latency and profile passes)
             "roofline": {
                 "kernel": "fk_spmv",
                 "bound": "hbm",
