@@ -24,7 +24,7 @@ SYMBOLS = (
     "ai_label_pairs", "ai_merge_associate", "ai_unique_points", "ai_affinity_build_sam", "ai_affinity_apply_camera",
     "ai_ctx_mem_info", "ai_abi_version", "ai_abi_sizeof", "ai_bench_copy",
 )
-ABI_VERSION = 4   # AI_ABI_VERSION of the header this binding was written against
+ABI_VERSION = 5   # AI_ABI_VERSION of the header this binding was written against
 
 
 class NcutOpts(C.Structure):

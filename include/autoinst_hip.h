@@ -29,12 +29,12 @@ typedef struct ai_ctx ai_ctx;
 typedef struct ai_csr ai_csr; /* device-resident symmetric affinity graph */
 
 /*
- * ABI version: bumped whenever a struct of this header changes size or a field changes meaning (4: round 4; 3 added
+ * ABI version: bumped whenever a struct of this header changes size or a field changes meaning (5: ai_ncut_stats gained restarted_solves and hist_retries; 4: round 4; 3 added
  * ai_ncut_opts.window_rows).  A binding checks ai_abi_version() == AI_ABI_VERSION and ai_abi_sizeof(which) against its own
  * struct sizes when it loads the library (autoinst_amd/_ffi.py does): a caller built against an older header would otherwise
  * pass a shorter ai_ncut_opts and have the library read past it.
  */
-#define AI_ABI_VERSION 4
+#define AI_ABI_VERSION 5
 int ai_abi_version(void);
 int64_t ai_abi_sizeof(int which); /* 0: ai_ncut_opts, 1: ai_ncut_stats; -1 otherwise */
 
