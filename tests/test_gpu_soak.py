@@ -2,8 +2,12 @@
 every repeat compared with the first -- labels, group counts, the number of solves and the largest accepted residual (the work
 counters differ, legitimately, in a repeat that solved a segment twice after the true-residual test: those repeats are logged).
 Round 3's race (a convergence check that read its pool entry through the scalar cache: one chunk in ~700 came out with other
-labels) was invisible to the 25-repeat test of the GPU suite and showed within a minute of this; `tools/soak_trace.py` is the
-variant that names the segments that differ."""
+labels) was invisible to the 25-repeat test of the GPU suite and showed within a minute of this.  Round 4's (the update kernel's
+exhausted-step freeze overwrote the size of T the check had reported; the packed histories of that segment then spilled onto the
+next one's row: one wrong cut in ~70 000) needed tens of minutes of `tools/soak_multi.sh` and the library's own true-residual test to
+be seen at all: a healthy run reports no repeated solve and no history row asked for again (both are written to
+gpurun_out/soak_failure.txt as they happen; AI_SOAK_KEEP_GOING=1 logs differences and goes on; AI_FLOW_GUARD_LOG=file keeps the
+evidence).  `tools/soak_trace.py` is the variant that names the segments that differ."""
 import os
 import threading
 import time
