@@ -1,6 +1,6 @@
 #!/bin/bash
 # Several soaks side by side on one GPU (one process each): tools/soak_multi.sh <seconds> <tag=lib[,ENV=VAL...]> ...
-# e.g. tools/soak_multi.sh 1500 cur=libautoinst_hip.so r3=ab_r3.so "A=ab_diag.so,AI_DBG_CHECK_R3=1,AI_DBG_NO_HELPER=1"
+# e.g. tools/soak_multi.sh 1000 a=libautoinst_hip.so "b=libautoinst_hip.so,AI_FLOW_GUARD_LOG=/root/repo/gpurun_out/soakm/guard_b.log" t=libautoinst_hip_trace.so  (make -C autoinst_amd/csrc trace)
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$R"; mkdir -p gpurun_out/soakm
 secs=$1; shift
 pids=()
