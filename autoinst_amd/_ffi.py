@@ -24,7 +24,7 @@ SYMBOLS = (
     "ai_label_pairs", "ai_merge_associate", "ai_unique_points", "ai_affinity_build_sam", "ai_affinity_apply_camera",
     "ai_ctx_mem_info", "ai_abi_version", "ai_abi_sizeof", "ai_bench_copy",
 )
-ABI_VERSION = 5   # AI_ABI_VERSION of the header this binding was written against
+ABI_VERSION = 6   # AI_ABI_VERSION of the header this binding was written against
 
 
 class NcutOpts(C.Structure):
@@ -39,6 +39,8 @@ class NcutStats(C.Structure):
         ("ms_total", C.c_double), ("ms_eigen", C.c_double), ("ms_spmv", C.c_double),
         ("ms_sweep", C.c_double), ("ms_rebuild", C.c_double), ("max_resid", C.c_double),
         ("restarted_solves", C.c_int64), ("hist_retries", C.c_int64),
+        ("max_true_resid", C.c_double), ("true_resid_limit", C.c_double),
+        ("accepted_above_limit", C.c_int64), ("check_timeouts", C.c_int64),
     ]
 
     def as_dict(self):
@@ -107,7 +109,13 @@ def load():
     lib.ai_merge_associate.argtypes = [vp, vp, vp, i64, vp, vp, i64, vp, dbl, i32, i32, C.c_int, vp, vp, vp, vp, vp]
     lib.ai_unique_points.argtypes = [vp, vp, i64, C.c_int, vp, P(i64)]
     if os.environ.get("AUTOINST_HIP_LIB") and not hasattr(lib, "ai_abi_version"):
-        # an older build selected for an A/B run (tools/): no ABI check, and the entry points it lacks stay unbound
+        # an older build selected for an A/B run (tools/): no ABI check, and the entry points it lacks stay unbound.  Only on request:
+        # a stale build picked up by accident must fail here with "rebuild", not later with an AttributeError or a wrong struct layout
+        if os.environ.get("AUTOINST_HIP_ALLOW_OLD_ABI") != "1":
+            raise AutoinstHipError(
+                f"{LIB_PATH} (selected through AUTOINST_HIP_LIB) has no ai_abi_version: it predates ABI 4.  Rebuild it, or set "
+                "AUTOINST_HIP_ALLOW_OLD_ABI=1 to load it unchecked for an A/B run (stats fields it lacks read as garbage)")
+        sys.stderr.write(f"autoinst_amd: WARNING: {LIB_PATH} loaded WITHOUT the ABI check (AUTOINST_HIP_ALLOW_OLD_ABI=1)\n")
         for name in SYMBOLS:
             if hasattr(lib, name) and name not in ("ai_version", "ai_last_error"):
                 getattr(lib, name).restype = C.c_int

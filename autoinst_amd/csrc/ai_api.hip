@@ -238,9 +238,13 @@ void ai_helper::start() {
       std::function<void()> f = std::move(job);
       has_job = false;
       lk.unlock();
-      f();
+      try {
+        f();
+      } catch (...) {  // nothing may escape a std::thread body (std::terminate): the submitter reads `failed` after wait() / try_done()
+        failed.store(true, std::memory_order_relaxed);
+      }
       lk.lock();
-      done = true;
+      done.store(true, std::memory_order_release);
       cv.notify_all();
     }
   });
@@ -250,12 +254,13 @@ void ai_helper::submit(std::function<void()> f) {
   std::lock_guard<std::mutex> lk(mu);
   job = std::move(f);
   has_job = true;
-  done = false;
+  failed.store(false, std::memory_order_relaxed);
+  done.store(false, std::memory_order_relaxed);
   cv.notify_all();
 }
 void ai_helper::wait() {
   std::unique_lock<std::mutex> lk(mu);
-  cv.wait(lk, [this] { return done; });
+  cv.wait(lk, [this] { return done.load(std::memory_order_acquire); });
 }
 void ai_helper::stop() {
   if (!th.joinable()) return;

@@ -6,6 +6,7 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <atomic>
 #include <thread>
 #include <string>
 #include <vector>
@@ -111,7 +112,9 @@ struct ai_helper {
   std::condition_variable cv;
   std::function<void()> job;
   bool has_job = false, quit = false;
-  volatile bool done = true;
+  std::atomic<bool> done{true};   // store-release by the worker after the job's last write, load-acquire by the poller (Flow::run)
+  std::atomic<bool> failed{false};  // the job threw (std::bad_alloc of a vector, ...): the submitter turns that into an error status
+  bool try_done() const { return done.load(std::memory_order_acquire); }
   void start();
   void submit(std::function<void()> f);  // the previous job must have been waited for
   void wait();

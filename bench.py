@@ -421,7 +421,9 @@ def main():
         stage_blocks = [torch.empty(B * (np_ + nf_), dtype=torch.float64, device=dev) for _ in range(K + 1)]
         views = lambda d: [(d[b * np_:(b + 1) * np_].view(shp_p), d[B * np_ + b * nf_:B * np_ + (b + 1) * nf_].view(shp_f)) for b in range(B)]
 
-    guard_counts = {"restarted_solves": 0, "hist_retries": 0, "calls": 0}   # (int += under the GIL)
+    # (int += under the GIL)
+    guard_counts = {"restarted_solves": 0, "hist_retries": 0, "accepted_above_limit": 0, "check_timeouts": 0, "calls": 0,
+                    "max_true_resid": 0.0, "max_resid_estimate": 0.0, "true_resid_limit": 0.0}
 
     def one_batch(k, profile=False, only_first=False, from_host=False, w=None, staged=None):
         # batch k of the rank's M batches, run by host thread w on that thread's context
@@ -447,6 +449,13 @@ def main():
         # and were solved again, waves whose packed histories failed their header check and were packed again -- over every call of the run
         guard_counts["restarted_solves"] += int(st.get("restarted_solves", 0))
         guard_counts["hist_retries"] += int(st.get("hist_retries", 0))
+        guard_counts["accepted_above_limit"] += int(st.get("accepted_above_limit", 0))
+        guard_counts["check_timeouts"] += int(st.get("check_timeouts", 0))
+        # how far from an eigenpair the cut vectors were: the largest TRUE residual ||M v - theta v|| / ||v|| of any pair that was cut
+        # (measured on the segment's own entries), beside the Lanczos estimate that stopped the solve and the bar the library enforces
+        guard_counts["max_true_resid"] = max(guard_counts["max_true_resid"], float(st.get("max_true_resid", 0.0)))
+        guard_counts["max_resid_estimate"] = max(guard_counts["max_resid_estimate"], float(st.get("max_resid", 0.0)))
+        guard_counts["true_resid_limit"] = float(st.get("true_resid_limit", 0.0))
         guard_counts["calls"] += 1
         return labs, ngs, st, nnz
 

@@ -29,12 +29,13 @@ typedef struct ai_ctx ai_ctx;
 typedef struct ai_csr ai_csr; /* device-resident symmetric affinity graph */
 
 /*
- * ABI version: bumped whenever a struct of this header changes size or a field changes meaning (5: ai_ncut_stats gained restarted_solves and hist_retries; 4: round 4; 3 added
+ * ABI version: bumped whenever a struct of this header changes size or a field changes meaning (6: ai_ncut_stats gained max_true_resid,
+ * true_resid_limit, accepted_above_limit and check_timeouts; 5: restarted_solves and hist_retries; 4: round 4; 3 added
  * ai_ncut_opts.window_rows).  A binding checks ai_abi_version() == AI_ABI_VERSION and ai_abi_sizeof(which) against its own
  * struct sizes when it loads the library (autoinst_amd/_ffi.py does): a caller built against an older header would otherwise
  * pass a shorter ai_ncut_opts and have the library read past it.
  */
-#define AI_ABI_VERSION 5
+#define AI_ABI_VERSION 6
 int ai_abi_version(void);
 int64_t ai_abi_sizeof(int which); /* 0: ai_ncut_opts, 1: ai_ncut_stats; -1 otherwise */
 
@@ -158,6 +159,14 @@ typedef struct {
                                reorthogonalisation gives 3e-7 there), so the labels never depend on the test */
   int64_t hist_retries;     /* waves whose packed Lanczos histories (device -> pinned host memory) failed their header check (size of T,
                                integer checksum) and were packed again; 0 in a healthy run, labels do not depend on it */
+  double max_true_resid;    /* largest TRUE residual ||M v - theta v|| / ||v|| of any Ritz pair that was cut (max_resid is the Lanczos
+                               ESTIMATE |beta_m s_m| that stopped the solve; this one is measured on the segment's own entries) */
+  double true_resid_limit;  /* the bar the call enforced on it: max(1e-6, 100 tol).  Above it a pair is solved again and cut only if the
+                               repeat reproduces the residual bit for bit (then it is the algorithm's own answer) */
+  int64_t accepted_above_limit; /* pairs cut with a true residual above the limit for that reason (dense blobs whose top eigenvalues
+                               cluster: 3e-7 without re-orthogonalisation); 0 on the benchmark's chunks */
+  int64_t check_timeouts;   /* convergence-check blocks that gave up waiting for their launch's scanning blocks (they judge nothing and
+                               the next launch judges instead); 0 unless the device is oversubscribed */
 } ai_ncut_stats;
 
 /*

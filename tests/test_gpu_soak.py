@@ -1,4 +1,5 @@
-"""Opt-in soak (-m gpu with AI_SOAK=1; AI_SOAK_SECONDS, default 180): the same batched calls again and again from two host threads,
+"""Soak, part of the default -m gpu suite since round 5 (AI_SOAK_SECONDS, default 75; tools/soak_multi.sh runs it for 1 000 s in several
+processes side by side): the same batched calls again and again from two host threads,
 every repeat compared with the first -- labels, group counts, the number of solves and the largest accepted residual (the work
 counters differ, legitimately, in a repeat that solved a segment twice after the true-residual test: those repeats are logged).
 Round 3's race (a convergence check that read its pool entry through the scalar cache: one chunk in ~700 came out with other
@@ -18,10 +19,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.skipif(os.environ.get("AI_SOAK") != "1", reason="opt-in: AI_SOAK=1 (about AI_SOAK_SECONDS = 180 s of GPU time)")
 def test_soak_two_threads_thin_tail_chunks():
+    """75 s by default: every repeat equals the first, no Ritz pair failed the true-residual test (restarted_solves), no packed history
+    row failed its header (hist_retries), no convergence check timed out -- so that the driver's own GPU run, on a box the builder
+    never touched, carries soak evidence for the round-4 freeze fix.  A non-zero counter fails the test (its evidence is in
+    gpurun_out/soak_failure.txt and, with AI_FLOW_GUARD_LOG, in that file); AI_SOAK_KEEP_GOING=1 logs and goes on."""
     from autoinst_amd import ncuts_api as api, synth
-    budget = float(os.environ.get("AI_SOAK_SECONDS", "180"))
+    budget = float(os.environ.get("AI_SOAK_SECONDS", "75"))
     # thin-tail chunks (the regime that raced: relists follow each other within microseconds at the end of a call) and one large one
     sets = [[(30000, 1), (24000, 2), (30000, 3), (18000, 4)], [(60000, 5), (9000, 6), (12000, 7), (200000, 0)]]
     nthreads = int(os.environ.get("AI_SOAK_THREADS", "2"))   # more threads / only the set with the large chunk: diagnosis runs
@@ -31,6 +35,9 @@ def test_soak_two_threads_thin_tail_chunks():
         sets = [sets[w % 2] for w in range(nthreads)]
     results = [None] * nthreads
     restarts = [0] * nthreads
+    hist_retries = [0] * nthreads
+    timeouts = [0] * nthreads
+    worst_true = [0.0] * nthreads
     errors = []
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
@@ -57,8 +64,11 @@ def test_soak_two_threads_thin_tail_chunks():
                 labs, ngs, st = api.ncuts_labels_batch(graphs, None, 0.03)
                 for g in graphs:
                     g.free()
+                timeouts[w] += st.get("check_timeouts", 0)
+                worst_true[w] = max(worst_true[w], st.get("max_true_resid", 0.0))
                 if st["hist_retries"]:
                     # a packed history row failed its header check and the wave's rows were packed again
+                    hist_retries[w] += st["hist_retries"]
                     note(logfile, f"thread {w}, repeat {reps}: {st['hist_retries']} wave(s) asked for their history rows again")
                 if st["restarted_solves"]:
                     # a Ritz pair failed the true-residual test and its segment was solved again: the labels must not show it
@@ -92,8 +102,20 @@ def test_soak_two_threads_thin_tail_chunks():
     for t in ts:
         t.join()
     note(progress, f"done: repeats {results}, repeated solves {restarts}, differences {len(errors)}")
+    import json
+    summary = {"seconds": budget, "threads": nthreads, "repeats": results, "chunk_cuts": 4 * sum(r or 0 for r in results),
+               "differences": len(errors), "restarted_solves": restarts, "hist_retries": hist_retries, "check_timeouts": timeouts,
+               "max_true_resid": max(worst_true), "lib": os.path.basename(os.environ.get("AUTOINST_HIP_LIB", "libautoinst_hip.so"))}
+    try:
+        with open(os.environ.get("AI_SOAK_RESULT") or os.path.join(root, "gpurun_out", "soak_result.json"), "a") as f:
+            f.write(json.dumps(summary) + "\n")
+    except OSError:
+        pass
+    print("soak: " + json.dumps(summary))
     if errors:
         raise errors[0]
     assert all(r and r >= 3 for r in results), results
     print(f"soak: {results} repeats of 4-chunk calls in {budget:.0f} s, every one equal to its first; solves repeated after the "
-          f"true-residual test: {restarts}")
+          f"true-residual test: {restarts}; history rows asked for again: {hist_retries}")
+    if not keep_going:
+        assert sum(restarts) == 0 and sum(hist_retries) == 0 and sum(timeouts) == 0, summary

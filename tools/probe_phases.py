@@ -1,6 +1,5 @@
 import os, sys, time, torch
-sys.path.insert(0, "/root/repo")
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from autoinst_amd import ncuts_api as api, synth
 from bench import CFG, N_POINTS
 dev = torch.device("cuda", 0)

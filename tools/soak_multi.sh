@@ -10,7 +10,7 @@ for spec in "$@"; do
   (
     IFS=, read -ra kv <<< "$envs"
     for e in "${kv[@]}"; do [ -n "$e" ] && export "$e"; done
-    export AUTOINST_HIP_LIB=$R/autoinst_amd/$lib AI_SOAK=1 AI_SOAK_SECONDS=$secs AI_SOAK_FAILFILE=$R/gpurun_out/soakm/$tag.failure
+    export AUTOINST_HIP_LIB=$R/autoinst_amd/$lib AI_SOAK=1 AI_SOAK_SECONDS=$secs AI_SOAK_FAILFILE=$R/gpurun_out/soakm/$tag.failure AI_SOAK_RESULT=$R/gpurun_out/soakm/$tag.result.json
     timeout -k 10 $((secs + 200)) python -m pytest tests/test_gpu_soak.py -m gpu -x -q -s > gpurun_out/soakm/$tag.log 2>&1
   ) &
   pids+=($!)
