@@ -205,6 +205,76 @@ def gpu_numa_cpus(torch, index: int):
     return node, near, f"{len(near)} of this process's {len(allowed)} CPUs are on the GPU's node {node}"
 
 
+# ----------------------------------------------------------------------------- rank start-up (multi-GPU runs)
+def _cpulist(cpus) -> str:
+    """{0,1,2,3,8,9} -> '0-3,8-9'"""
+    out, run = [], []
+    for c in sorted(cpus):
+        if run and c == run[-1] + 1:
+            run.append(c)
+        else:
+            if run:
+                out.append(run)
+            run = [c]
+    if run:
+        out.append(run)
+    return ",".join(str(r[0]) if len(r) == 1 else f"{r[0]}-{r[-1]}" for r in out)
+
+
+def rank_startup_info(rank: int, local_rank: int, torch=None, numa=None) -> dict:
+    """What a rank is running on, gathered into rank 0's JSON line (`ranks`): the first thing to look at when an N-GPU run is slow or
+    hangs -- which device, which NUMA node, which CPUs each rank got."""
+    import socket
+    cpus = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else set(range(os.cpu_count() or 1))
+    info = {"rank": rank, "local_rank": local_rank, "pid": os.getpid(), "host": socket.gethostname(), "cpus": len(cpus), "cpu_list": _cpulist(cpus)}
+    if torch is not None and torch.cuda.is_available():
+        try:
+            pr = torch.cuda.get_device_properties(local_rank)
+            info.update({"device": pr.name, "gcn_arch": getattr(pr, "gcnArchName", None), "hbm_gb": round(pr.total_memory / 2 ** 30, 1),
+                         "pci": "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)})
+        except Exception as e:  # noqa: BLE001 -- diagnosis only
+            info["device_error"] = f"{type(e).__name__}: {e}"
+    if numa is not None:
+        info.update({"gpu_numa_node": numa[0], "numa_note": numa[2]})
+    return info
+
+
+def first_collective(dist, torch, device, rank: int, world: int, limit_s: float, what: str) -> float:
+    """The first collective of the run, bounded: an 8-byte all_reduce that must return within `limit_s` seconds.  More than one
+    rank has never met RCCL on this pool (the builder has one GPU), so the first exchange is where a wrong rendezvous, a GPU that is
+    not there or an IPC problem would show -- as a hang.  A watchdog thread turns that into a message that names the rank and a
+    non-zero exit (the launcher -- `self_launch` or torchrun -- then ends the other ranks); nothing is re-executed.  Returns ms."""
+    import threading
+    done = threading.Event()
+
+    def watchdog():
+        if not done.wait(limit_s):
+            sys.stderr.write(f"bench.py: rank {rank} of {world} (pid {os.getpid()}): the first {what} collective (8-byte all_reduce) did not complete "
+                             f"within {limit_s:.0f} s -- rendezvous at {os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}; "
+                             "a rank that is missing, a GPU that is not visible or HSA_ENABLE_IPC_MODE_LEGACY != 0 are the usual causes\n")
+            sys.stderr.flush()
+            os._exit(75)
+
+    threading.Thread(target=watchdog, daemon=True, name="first-collective-watchdog").start()
+    t0 = time.perf_counter()
+    t = torch.ones(1, dtype=torch.int64, device=device)
+    dist.all_reduce(t)
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    got = int(t.item())
+    done.set()
+    if got != world:
+        raise SystemExit(f"bench.py: rank {rank}: the first all_reduce returned {got}, expected the world size {world}")
+    return 1e3 * (time.perf_counter() - t0)
+
+
+def gather_rank_infos(dist, info: dict, world: int, group=None):
+    """every rank's start-up record on every rank (object collective on a gloo group: control plane, not the data path)"""
+    out = [None] * world
+    dist.all_gather_object(out, info, group=group)
+    return out
+
+
 # ----------------------------------------------------------------------------- self-launch
 def _free_port() -> int:
     import socket
@@ -235,9 +305,10 @@ def self_launch(n: int, argv) -> int:
     try:
         while True:
             rcs = [p.poll() for p in procs]
-            bad = [rc for rc in rcs if rc not in (None, 0)]
+            bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
             if bad:
-                code = bad[0]
+                code = bad[0][1]
+                sys.stderr.write("bench.py: " + ", ".join(f"rank {r} exited with code {rc}" for r, rc in bad) + f" (of {n} ranks); ending the others\n")
                 break
             if all(rc == 0 for rc in rcs):
                 break
@@ -265,8 +336,12 @@ def dry_run(args, world, rank):
     import torch
     import torch.distributed as dist
     from autoinst_amd import sharding
+    infos, first_ms = [rank_startup_info(rank, int(os.environ.get("LOCAL_RANK", "0")))], None
     if world > 1:
-        dist.init_process_group("gloo")
+        import datetime
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))
+        first_ms = first_collective(dist, torch, torch.device("cpu"), rank, world, float(os.environ.get("AI_BENCH_FIRST_COLLECTIVE_S", "120")), "gloo")
+        infos = gather_rank_infos(dist, infos[0], world)
     rng = np.random.default_rng(0)
     nchunks = world * args.in_flight * args.batch
     sizes = np.exp(rng.uniform(np.log(3_000), np.log(30_000), nchunks)).astype(int).tolist()   # cfg3's chunk-size mix: an UNEVEN deal
@@ -320,7 +395,7 @@ def dry_run(args, world, rank):
                                   "cost_max_over_mean": max(loads) / mean_load, "predicted_efficiency_from_imbalance": mean_load / max(loads)},
                           "root_ms_per_step": {"pack": 1e3 * t_pack / args.steps, "exchange_calls": 1e3 * t_gather / args.steps,
                                                "wait_for_parse": 1e3 * t_parse / args.steps},
-                          "label_bytes_per_step": int(4 * sum(sizes))}), flush=True)
+                          "label_bytes_per_step": int(4 * sum(sizes)), "ranks": infos, "first_collective_ms": first_ms}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -363,15 +438,26 @@ def main():
     if world > 1:
         # one rank per GPU on one node: keep the rank's threads (two feeding threads, their helper threads, the gather's parser) and
         # the pinned memory they first-touch on the CPUs of the GPU's NUMA node
+        _numa = None
         try:
-            _node, _near, _note = gpu_numa_cpus(torch, local_rank)
-            if _near and len(_near) >= 8:
-                os.sched_setaffinity(0, _near)
+            _numa = gpu_numa_cpus(torch, local_rank)
+            if _numa[1] and len(_numa[1]) >= 8:
+                os.sched_setaffinity(0, _numa[1])
         except OSError:
             pass
         import datetime
         # a rank that dies leaves the others in a collective: the timeout turns that into a failure
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=600))
+        # control plane on gloo (start-up records); then the first RCCL collective, bounded and named (first_collective)
+        ctl = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=300))
+        rank_infos = gather_rank_infos(dist, rank_startup_info(rank, local_rank, torch, _numa), world, group=ctl)
+        first_ms = first_collective(dist, torch, torch.device("cuda", local_rank), rank, world, float(os.environ.get("AI_BENCH_FIRST_COLLECTIVE_S", "180")), "RCCL")
+        if rank == 0:
+            for ri in rank_infos:
+                sys.stderr.write("bench.py: " + json.dumps(ri) + "\n")
+            sys.stderr.write(f"bench.py: first RCCL all_reduce over {world} ranks: {first_ms:.1f} ms\n")
+    else:
+        rank_infos, first_ms = [rank_startup_info(rank, local_rank, torch)], None
 
     from autoinst_amd import ncuts_api as api
     from autoinst_amd import sharding, synth
@@ -694,6 +780,8 @@ def main():
             "data": "synthetic",
             "rccl_ranks": dist.get_world_size() if world > 1 else 1,
             "backend": dist.get_backend() if world > 1 else "none",
+            "ranks": rank_infos,                      # per rank: device, PCI id, GPU NUMA node, CPUs the rank may run on
+            "first_collective_ms": first_ms,          # the bounded first RCCL all_reduce (None at N = 1)
             "config": {"workload": "configs[1]: single 200k-point surface chunk, TARL(96-d)+Spatial affinities, "
                                    f"alpha=1 theta=0.5 T=0.03; per GPU per step {M} batched calls of {B} chunks (one pool of iterating segments each) taken from a queue by {K} host threads",
                        "n_points": N_POINTS, "nnz": int(nnz), "chunks_per_step": world * M * B, "threads_per_gpu": K, "chunks_per_batch": B, "batches_per_step": M,

@@ -49,6 +49,9 @@ def test_bench_launches_its_own_ranks_dry():
     line = json.loads(lines[0])
     assert line["dry"] is True and line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["backend"] == "gloo"
     assert line["steps"] == 3 and line["scaling"] == "weak"
+    # every rank's start-up record is in rank 0's line, and the first collective was bounded and timed
+    assert [r["rank"] for r in line["ranks"]] == [0, 1] and all(r["cpus"] >= 1 and r["pid"] > 0 for r in line["ranks"])
+    assert line["first_collective_ms"] is not None and line["first_collective_ms"] >= 0.0
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry"], env=dict(env, WORLD_SIZE="1", RANK="0"),
                          capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)
@@ -62,3 +65,41 @@ def test_bench_self_launch_propagates_a_failing_rank():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=dict(env, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""), capture_output=True, text=True, timeout=300)
     assert p.returncode != 0
+    assert "exited with code" in p.stderr and "rank" in p.stderr   # the parent names the rank that failed
+
+
+def test_first_collective_that_never_completes_ends_the_rank_non_zero_and_names_it(tmp_path):
+    """One of two ranks never arrives: the rank that is there must not hang in its first collective -- the watchdog ends it with a
+    message that names the rank (here the rendezvous itself times out first or the watchdog fires: either way non-zero, bounded)."""
+    import socket
+    import subprocess
+    import sys
+    import time
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    code = (
+        "import os, sys, time, threading\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import torch, torch.distributed as dist, datetime\n"
+        "import bench\n"
+        "dist.init_process_group('gloo', rank=int(os.environ['RANK']), world_size=2, timeout=datetime.timedelta(seconds=120))\n"
+        "if dist.get_rank() == 1:\n"
+        "    time.sleep(60)\n"      # arrives at the rendezvous but never at the collective
+        "    os._exit(0)\n"
+        "bench.first_collective(dist, torch, torch.device('cpu'), 0, 2, 3.0, 'gloo')\n"
+        "print('NOT REACHED')\n"
+    )
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    t0 = time.time()
+    out0, err0 = procs[0].communicate(timeout=120)
+    took = time.time() - t0
+    procs[1].kill()
+    procs[1].wait()
+    assert procs[0].returncode == 75, (procs[0].returncode, err0[-1500:])
+    assert "rank 0 of 2" in err0 and "did not complete" in err0 and "NOT REACHED" not in out0
+    assert took < 60

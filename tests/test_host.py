@@ -78,6 +78,60 @@ def test_gather_labels_world_size_2_gloo(tmp_path):
     assert "GATHER_OK" in outs[0]
 
 
+_WORKER4 = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from autoinst_amd import sharding
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+# configs[2]'s chunk-size mix (3k-30k points, log-uniform: an UNEVEN deal), three steps through the asynchronous gather as bench.py
+# issues it (step s + 1's exchange before step s's result is waited for); rank 3 holds NOTHING in step 1 (an empty payload)
+rng = np.random.default_rng(5)
+sizes = np.exp(rng.uniform(np.log(3000), np.log(30000), 13)).astype(int).tolist()
+deal = sharding.lpt_assign(sizes, world)
+assert sorted(c for d in deal for c in d) == list(range(len(sizes)))
+pending, outs = None, []
+for step in range(3):
+    mine = [] if (step == 1 and rank == 3) else deal[rank]
+    local = {c: ((np.arange(sizes[c], dtype=np.int32) + step) % (c + 2)).astype(np.int32) for c in mine}
+    fut = sharding.gather_labels_async(local)
+    if pending is not None:
+        outs.append(pending.result() if rank == 0 else None)
+    pending = fut
+    assert (fut is None) == (rank != 0)
+outs.append(pending.result() if rank == 0 else None)
+if rank == 0:
+    for step, out in enumerate(outs):
+        want = [c for r, d in enumerate(deal) for c in d if not (step == 1 and r == 3)]
+        assert sorted(out) == sorted(want), (step, sorted(out))
+        for c in want:
+            assert np.array_equal(out[c], (np.arange(sizes[c], dtype=np.int32) + step) % (c + 2)), (step, c)
+    print("GATHER4_OK", [len(d) for d in deal])
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_gather_labels_async_world_size_4_uneven_mix_and_an_empty_rank(tmp_path):
+    """World size 4 over gloo: the uneven cfg3 chunk mix dealt by LPT, three pipelined steps through `gather_labels_async`, one
+    rank's payload empty in one step (a rank that ran out of chunks must still take part in both collectives)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "w4.py"
+    script.write_text(_WORKER4)
+    procs = []
+    for r in range(4):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="4", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "GATHER4_OK" in outs[0]
+
+
 def test_run_chunks_argument_checks():
     """`sharding.run_chunks` without work does not touch the GPU; bad thread / batch counts raise."""
     assert sharding.run_chunks([]) == []
