@@ -367,12 +367,12 @@ __global__ __launch_bounds__(AI_BLOCK) void k_weights(const int32_t* __restrict_
 // 16 Morton-consecutive rows; their ~600 entries touch only ~200 DISTINCT columns (consecutive rows share their 27
 // neighbour cells), so the block collects that set in an LDS hash table, stages the feature rows of the set ONCE per
 // 16-dimension slab, and every entry then reads its neighbour's slab from LDS.
-#define AW_TABLE 512   // hash slots
 #define AW_SLAB 16     // dimensions per slab
 #define AW_SLAB_LOG 4
 
+template <int AW_TABLE, int AW_TSHIFT>
 __device__ __forceinline__ int aw_find(const int32_t* keys, int32_t c) {
-  unsigned h = ((unsigned)c * 2654435761u) >> 23;  // 9 bits
+  unsigned h = ((unsigned)c * 2654435761u) >> AW_TSHIFT;  // log2(AW_TABLE) bits
   for (int i = 0; i < AW_TABLE; ++i) {
     const int32_t k = keys[h];
     if (k == c) return (int)h;
@@ -440,26 +440,33 @@ __device__ unsigned long long g_aw_phase[8];
 #else
 #define AW_STAMP(k) do { } while (0)
 #endif
-#define AW_ECAP 2048   // entries of a tile whose hash slot is remembered (more: fallback)
-template <int AW_MAXD, int ACC>
-__global__ __launch_bounds__(AI_BLOCK, 3) void k_weights_lanes(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+#define AW_ECAP 2048   // entries of a 16-row tile whose hash slot is remembered (more: fallback); twice that for 32 rows
+// NT = threads per block = 16 x the rows of a tile.  256: 16-row tiles, ~200 distinct columns, 32 KB slabs, three blocks per CU.
+// 512 (round 5): 32-row tiles -- consecutive Morton rows share their neighbour cells, so 32 rows touch ~300 distinct columns, not
+// 2 x 200: a quarter fewer staged bytes per row, and the staging wait is what the kernel's time is -- 48 KB slabs,
+// two blocks per CU (the same 96 KB of slabs in flight per CU), 128 registers per lane instead of 168.
+template <int NT, int AW_MAXD, int ACC>
+__global__ __launch_bounds__(NT, (NT == 256 ? 3 : 4)) void k_weights_lanes(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                                double* __restrict__ val, const int32_t* __restrict__ orig, int64_t n,
                                                                const double* __restrict__ tarl, int32_t tdim,
                                                                const uint8_t* __restrict__ notarl, const double* __restrict__ dino,
                                                                int32_t ddim, double alpha, double theta, double gamma) {
-  constexpr int AW_ROWS = AI_BLOCK / 16;                    // 16 lanes per row
-  constexpr int AW_STAGE = (AW_MAXD * AW_SLAB) / AI_BLOCK;  // staged values per thread per slab
+  constexpr int AW_ROWS = NT / 16;                    // 16 lanes per row
+  constexpr int AW_STAGE = (AW_MAXD * AW_SLAB) / NT;  // staged values per thread per slab
   constexpr int EPT = ACC / 8;                              // finished entries per lane (epilogue)
-  static_assert(AW_MAXD < AW_TABLE && ACC % 8 == 0 && AW_SLAB == 16 && AW_TABLE == 2 * AI_BLOCK, "tile shape");
+  constexpr int AW_TABLE = 2 * NT;                          // hash slots
+  constexpr int AW_TSHIFT = (NT == 256) ? 23 : 22;          // 32 - log2(AW_TABLE)
+  static_assert(AW_MAXD < AW_TABLE && ACC % 8 == 0 && AW_SLAB == 16 && (NT == 256 || NT == 512), "tile shape");
   // the hash table is dead once every entry knows its staged position: it shares its LDS with the slab buffer
   __shared__ __attribute__((aligned(16))) double xs[AW_MAXD * AW_SLAB];
   int32_t* const keys = reinterpret_cast<int32_t*>(xs);
   uint16_t* const cidx = reinterpret_cast<uint16_t*>(keys + AW_TABLE);
   static_assert(sizeof(double) * AW_MAXD * AW_SLAB >= AW_TABLE * 6, "the slab buffer holds the hash table");
-  __shared__ uint16_t eslot[AW_ECAP];  // hash slot, then staged position, of every entry of the tile
+  constexpr int ECAP = AW_ECAP * (NT / 256);
+  __shared__ uint16_t eslot[ECAP];  // hash slot, then staged position, of every entry of the tile
   __shared__ int32_t corig[AW_MAXD];
   __shared__ int32_t srow[AW_ROWS + 1];
-  __shared__ int32_t wcnt[AI_BLOCK / 64];
+  __shared__ int32_t wcnt[NT / 64];
   __shared__ int32_t s_over;
 #ifdef AW_PHASES
   unsigned long long aw_t = wall_clock64();
@@ -472,19 +479,19 @@ __global__ __launch_bounds__(AI_BLOCK, 3) void k_weights_lanes(const int32_t* __
   const bool use_t = (theta != 0.0) && tarl != nullptr;
   const bool use_d = (gamma != 0.0) && dino != nullptr;
   keys[tid] = -1;
-  keys[tid + AI_BLOCK] = -1;
+  keys[tid + NT] = -1;
   if (tid <= nrows) srow[tid] = rowptr[r0 + tid];
   if (tid == 0) s_over = 0;
   __syncthreads();
   const int32_t e0 = srow[0], e1 = srow[nrows];
   // ---- distinct columns of the tile (every row is its own neighbour, so the rows themselves are in the set): open
   // addressing in LDS; the slot an entry ended in is remembered, so that it is probed once
-  if (e1 - e0 > AW_ECAP) {
+  if (e1 - e0 > ECAP) {
     if (tid == 0) s_over = 1;
   } else {
-    for (int32_t e = e0 + tid; e < e1; e += AI_BLOCK) {
+    for (int32_t e = e0 + tid; e < e1; e += NT) {
       const int32_t c = col[e];
-      unsigned h = ((unsigned)c * 2654435761u) >> 23;
+      unsigned h = ((unsigned)c * 2654435761u) >> AW_TSHIFT;
       bool done = false;
       for (int i = 0; i < AW_TABLE && !done; ++i) {
         const int32_t old = atomicCAS(&keys[h], -1, c);
@@ -515,7 +522,7 @@ __global__ __launch_bounds__(AI_BLOCK, 3) void k_weights_lanes(const int32_t* __
     __syncthreads();
     int pos = incl - mine;
 #pragma unroll
-    for (int w = 0; w < AI_BLOCK / 64; ++w) {
+    for (int w = 0; w < NT / 64; ++w) {
       if (w < (tid >> 6)) pos += wcnt[w];
       nd += wcnt[w];
     }
@@ -532,7 +539,7 @@ __global__ __launch_bounds__(AI_BLOCK, 3) void k_weights_lanes(const int32_t* __
   }
   if (nd > AW_MAXD || s_over) {
     // ---- fallback (dense clouds: more than AW_MAXD distinct neighbours): one thread per entry, rows from global memory
-    for (int32_t e = e0 + tid; e < e1; e += AI_BLOCK) {
+    for (int32_t e = e0 + tid; e < e1; e += NT) {
       int lo = 0, hi = nrows - 1;
       while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -548,7 +555,7 @@ __global__ __launch_bounds__(AI_BLOCK, 3) void k_weights_lanes(const int32_t* __
     return;
   }
   __syncthreads();
-  for (int i = tid; i < e1 - e0; i += AI_BLOCK) eslot[i] = cidx[eslot[i]];  // hash slot -> staged position
+  for (int i = tid; i < e1 - e0; i += NT) eslot[i] = cidx[eslot[i]];  // hash slot -> staged position
   __syncthreads();
   AW_STAMP(1);  // numbering, slot -> position
   const int l = tid & 15, g = tid >> 4;  // lane in the row group, row of the tile
@@ -557,7 +564,7 @@ __global__ __launch_bounds__(AI_BLOCK, 3) void k_weights_lanes(const int32_t* __
   const int32_t p0 = rlive ? srow[g] : 0, p1 = rlive ? srow[g + 1] : 0;
   int maxlen = 0;
   for (int r = 0; r < nrows; ++r) maxlen = max(maxlen, srow[r + 1] - srow[r]);  // block-uniform
-  const uint32_t ci = rlive ? (uint32_t)cidx[aw_find(keys, (int32_t)(r0 + g))] : 0u;
+  const uint32_t ci = rlive ? (uint32_t)cidx[aw_find<AW_TABLE, AW_TSHIFT>(keys, (int32_t)(r0 + g))] : 0u;
   const bool nti = (use_t && rlive) ? (notarl[r0 + g] != 0) : false;
   for (int base = 0; base < maxlen; base += 2 * ACC) {
     const int rounds = min(ACC, (maxlen - base + 1) >> 1);  // block-uniform number of entry pairs in this round
@@ -597,7 +604,7 @@ __global__ __launch_bounds__(AI_BLOCK, 3) void k_weights_lanes(const int32_t* __
       uint32_t roff[AW_STAGE / 2];
 #pragma unroll
       for (int i = 0; i < AW_STAGE / 2; ++i) {
-        const int p = tid + AI_BLOCK * i;
+        const int p = tid + NT * i;
         const int c = min(p >> 3, nd - 1);
         roff[i] = (uint32_t)(((uint64_t)(uint32_t)corig[c] * (uint64_t)dim) >> 1) + (uint32_t)(p & 7);
       }
@@ -606,7 +613,7 @@ __global__ __launch_bounds__(AI_BLOCK, 3) void k_weights_lanes(const int32_t* __
 #pragma unroll
         for (int i = 0; i < AW_STAGE / 2; ++i) {
           const char* src = fs + ((uint64_t)roff[i] << 4);
-          double* dst = xs + 2 * ((tid & ~63) + AI_BLOCK * i);  // wave-uniform; lane l lands at dst + 2 l
+          double* dst = xs + 2 * ((tid & ~63) + NT * i);  // wave-uniform; lane l lands at dst + 2 l
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                            (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
@@ -918,9 +925,17 @@ extern "C" int ai_affinity_build_sam(ai_ctx* ctx, const double* xyz, int64_t n, 
                        (uint64_t)n * (uint64_t)std::max(has_t ? tarl_dim : 0, has_d ? dino_dim : 0) < ((uint64_t)1 << 33);  // staging offsets: 32 bits of 16-byte units
     if (tiled) {
       // LDS-tiled: every distinct neighbour's feature row is read once per 16-row tile
-      hipLaunchKernelGGL((k_weights_lanes<256, 32>), dim3((unsigned)((n + 15) / 16)), dim3(AI_BLOCK), 0, st, (const int32_t*)A->rowptr,
-                         (const int32_t*)A->col, A->val, (const int32_t*)A->orig, n, d_tarl, tarl_dim, (const uint8_t*)notarl.p, d_dino, dino_dim,
-                         alpha, theta, gamma);
+      // 32-row tiles (512 threads) by default; AI_WEIGHTS_TILE=16 selects the 16-row form of rounds 2-4 (same bits: an entry's sum
+      // does not depend on the tile it is computed in)
+      static const int tile16 = getenv("AI_WEIGHTS_TILE") ? atoi(getenv("AI_WEIGHTS_TILE")) != 32 : 1;
+      if (tile16)
+        hipLaunchKernelGGL((k_weights_lanes<256, 256, 32>), dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, (const int32_t*)A->rowptr,
+                           (const int32_t*)A->col, A->val, (const int32_t*)A->orig, n, d_tarl, tarl_dim, (const uint8_t*)notarl.p, d_dino, dino_dim,
+                           alpha, theta, gamma);
+      else
+        hipLaunchKernelGGL((k_weights_lanes<512, 384, 32>), dim3((unsigned)((n + 31) / 32)), dim3(512), 0, st, (const int32_t*)A->rowptr,
+                           (const int32_t*)A->col, A->val, (const int32_t*)A->orig, n, d_tarl, tarl_dim, (const uint8_t*)notarl.p, d_dino, dino_dim,
+                           alpha, theta, gamma);
     } else {
     // wave per row (SAM factor, widths that are not multiples of 16): the row's own features stay in registers
     // when the width is the reference's (96-d TARL, 384-d DINO);

@@ -411,6 +411,7 @@ def main():
     ap.add_argument("--cpu-50k", action="store_true", help="cpu_baseline: the single-process 50k-point oracle run on this host (~3 min) even when the pool leg took more than 200 s")
     ap.add_argument("--no-cpu-50k", action="store_true", help="cpu_baseline: skip the single-process 50k-point oracle run on this host")
     ap.add_argument("--batches", type=int, default=0, help="batched calls per GPU per step (default: one per host thread)")
+    ap.add_argument("--window-chunks", type=int, default=0, help="admission window of a batched call in chunks (0: the library's default, 4.8 M rows = 24 chunks): chunks beyond it wait inside the call and join as earlier ones finish")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-inputs", action="store_true", help="skip the pinned-host-input leg (value_host_inputs)")
     ap.add_argument("--no-latency-all", action="store_true", help="skip the one-chunk-alone pass over all chunks of the step (profiled runs)")
@@ -526,7 +527,7 @@ def main():
                 lab, ng, st = api.ncuts_labels(graphs[0], N_POINTS, CFG["T"], time_spmv=profile)
                 labs, ngs = [lab], [ng]
             else:
-                labs, ngs, st = api.ncuts_labels_batch(graphs, None, CFG["T"], time_spmv=profile)
+                labs, ngs, st = api.ncuts_labels_batch(graphs, None, CFG["T"], time_spmv=profile, window_rows=(args.window_chunks * N_POINTS) or None)
         finally:
             nnz = graphs[0].nnz
             for g in graphs:
