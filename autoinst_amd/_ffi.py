@@ -41,6 +41,7 @@ class NcutStats(C.Structure):
         ("restarted_solves", C.c_int64), ("hist_retries", C.c_int64),
         ("max_true_resid", C.c_double), ("true_resid_limit", C.c_double),
         ("accepted_above_limit", C.c_int64), ("check_timeouts", C.c_int64),
+        ("spmv_blocks", C.c_int64), ("spmv_blocks_idle", C.c_int64),
     ]
 
     def as_dict(self):

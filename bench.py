@@ -705,9 +705,11 @@ def main():
     t_ov0 = time.perf_counter()
     res_ov, _ = run_steps(1, profile="clock")
     t_ov = time.perf_counter() - t_ov0
-    ov = {"launches": 0, "bytes": 0.0, "ms": 0.0}
+    ov = {"launches": 0, "bytes": 0.0, "ms": 0.0, "blocks": 0, "blocks_idle": 0}
     for k in range(M):
         s = res_ov[k][2]
+        ov["blocks"] += int(s.get("spmv_blocks", 0))
+        ov["blocks_idle"] += int(s.get("spmv_blocks_idle", 0))
         ov["launches"] += int(s["lanczos_steps"])
         ov["bytes"] += spmv_bytes(int(s["spmv_rows"]), int(s["spmv_nnz"]), int(s["lanczos_steps"]))
         ov["ms"] += s["ms_spmv"]
@@ -827,7 +829,10 @@ def main():
                 "traffic_source": traffic_src,
                 "overlapped": {"launches": ov["launches"], "avg_launch_us": 1e3 * ov["ms"] / max(ov["launches"], 1),
                                "bytes_per_launch_avg": ov["bytes"] / max(ov["launches"], 1), "achieved_gbps": ach_ov,
-                               "step_wall_ms_while_stamping": 1e3 * t_ov},
+                               "step_wall_ms_while_stamping": 1e3 * t_ov,
+                               # blocks dispatched for segments that had frozen since the task lists were written (they end after a record
+                               # and a flag load; the lists are rewritten at the next relist)
+                               "blocks": ov["blocks"], "blocks_idle": ov["blocks_idle"], "blocks_idle_frac": ov["blocks_idle"] / max(ov["blocks"], 1)},
                 "solo": {"launches": launches, "avg_launch_us": 1e3 * stp["ms_spmv"] / max(launches, 1),
                          "bytes_per_launch_avg": b / max(launches, 1), "achieved_gbps": ach_solo},
                 "timer": "every SpMV launch stamps its own span (first block in .. last block out) on the device clock (wall_clock64)",

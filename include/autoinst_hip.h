@@ -30,7 +30,7 @@ typedef struct ai_csr ai_csr; /* device-resident symmetric affinity graph */
 
 /*
  * ABI version: bumped whenever a struct of this header changes size or a field changes meaning (6: ai_ncut_stats gained max_true_resid,
- * true_resid_limit, accepted_above_limit and check_timeouts; 5: restarted_solves and hist_retries; 4: round 4; 3 added
+ * true_resid_limit, accepted_above_limit, check_timeouts, spmv_blocks and spmv_blocks_idle; 5: restarted_solves and hist_retries; 4: round 4; 3 added
  * ai_ncut_opts.window_rows).  A binding checks ai_abi_version() == AI_ABI_VERSION and ai_abi_sizeof(which) against its own
  * struct sizes when it loads the library (autoinst_amd/_ffi.py does): a caller built against an older header would otherwise
  * pass a shorter ai_ncut_opts and have the library read past it.
@@ -167,6 +167,9 @@ typedef struct {
                                cluster: 3e-7 without re-orthogonalisation); 0 on the benchmark's chunks */
   int64_t check_timeouts;   /* convergence-check blocks that gave up waiting for their launch's scanning blocks (they judge nothing and
                                the next launch judges instead); 0 unless the device is oversubscribed */
+  int64_t spmv_blocks;      /* only with opts->reserved bit 0 or 1: blocks dispatched by the stamped SpMV launches ... */
+  int64_t spmv_blocks_idle; /* ... and how many of them found their segment frozen since the task lists were written (they end after a
+                               record and a flag load; the lists are rewritten at the next relist) */
 } ai_ncut_stats;
 
 /*

@@ -103,11 +103,14 @@ def lanczos(w, ids, start=None, tol=1e-10, max_iter=4000, n_extra=0):
 def run_variant(A, n, T, variant, inherit=True):
     """The whole recursion with one start-vector rule.  Returns stats and canonical labels."""
     hashv = variant == "hash"
+    dev = variant.startswith("dev")   # devP: like pP, but what the device would form: (sum of the Ritz vectors)|child * sqrt(n_parent) + 0.01 * hash
+    if dev:
+        variant = "p" + variant[3:]
     rr = variant.startswith("rr")    # rrK: Rayleigh-Ritz in the child over the parent's K top Ritz vectors (Fiedler included), K extra SpMVs
     with_f = variant.endswith("f") or rr
     p = 0 if hashv else int(variant[2:]) + 1 if rr else int(variant[1:].rstrip("f"))
     n_extra = 0 if hashv else max(p - 2, 0)
-    st = {"variant": variant, "solves": 0, "steps": 0, "row_steps": 0, "warm_solves": 0, "per_solve": []}
+    st = {"variant": ("dev" + variant[1:]) if dev else variant, "solves": 0, "steps": 0, "row_steps": 0, "warm_solves": 0, "per_solve": []}
     groups = []
 
     def rec(w, lab, warm):
@@ -148,6 +151,8 @@ def run_variant(A, n, T, variant, inherit=True):
                 wv += fied[0] * fied[1]
             if not extra and not with_f:
                 wv = None
+        if dev and wv is not None:
+            wv = wv * np.sqrt(nn) + 0.01 * gm.start_vector(lab)
         rec(w[mask][:, mask], lab[mask], None if wv is None else wv[mask])
         rec(w[~mask][:, ~mask], lab[~mask], None if wv is None else wv[~mask])
 
