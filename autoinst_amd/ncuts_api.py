@@ -250,14 +250,17 @@ def _opts(tol, max_iter, check_every, time_spmv=False, window_rows=None):
 
 
 def ncuts_labels(graph: DeviceGraph, num_points_orig: int, T: float, split_lim: float = SPLIT_LIM, *,
-                 tol=None, max_iter=None, check_every=None, time_spmv=False):
-    """Run the recursion on a device graph; returns (labels[int32 n], n_groups, stats dict)."""
+                 tol=None, max_iter=None, check_every=None, time_spmv=False, ctx: Context | None = None):
+    """Run the recursion on a device graph; returns (labels[int32 n], n_groups, stats dict).
+
+    ``ctx``: the context (streams, workspace) the call runs on; default: the one that built the graph.  A context serves ONE thread at a
+    time: a thread that cuts graphs another thread's context built passes its own."""
     global _last_stats
     lab = np.empty(graph.n, dtype=np.int32)
     ng = C.c_int32()
     stats = _ffi.NcutStats()
     o = _opts(tol, max_iter, check_every, time_spmv)
-    status = _ffi.load().ai_ncut(graph.ctx._h, graph._h, int(num_points_orig), float(T), float(split_lim),
+    status = _ffi.load().ai_ncut((ctx or graph.ctx)._h, graph._h, int(num_points_orig), float(T), float(split_lim),
                                  C.byref(o), lab.ctypes.data, C.byref(ng), C.byref(stats))
     _last_stats = stats.as_dict()   # filled on AI_ERR_NO_CONVERGENCE too
     _ffi.check(status, "ai_ncut")
@@ -265,19 +268,22 @@ def ncuts_labels(graph: DeviceGraph, num_points_orig: int, T: float, split_lim: 
 
 
 def ncuts_labels_batch(graphs, num_points_orig=None, T=CONFIG["T"], split_lim=SPLIT_LIM, *, tol=None, max_iter=None,
-                       check_every=None, time_spmv=False, window_rows=None):
+                       check_every=None, time_spmv=False, window_rows=None, ctx: Context | None = None):
     """`ncuts_labels` for several independent chunks in ONE call (``ai_ncut_batch``).
 
     The connected segments of all chunks iterate in one pool and share every kernel launch, which is
     how a GPU is kept busy by a map's many chunks; chunks beyond ``window_rows`` points wait inside the
     call and are admitted as earlier ones finish.  Returns ([labels_c], [n_groups_c], stats);
     each chunk's result is what `ncuts_labels` gives for it alone.
+
+    ``ctx``: the context the call runs on (default: the one that built the first graph).  A context serves ONE thread at a time, so a
+    thread that cuts graphs a builder thread's context has built passes its own (`sharding.run_chunks`, `bench.py`).
     """
     global _last_stats
     graphs = list(graphs)
     if not graphs:
         return [], [], None
-    ctx = graphs[0].ctx
+    ctx = ctx or graphs[0].ctx
     k = len(graphs)
     norig = [g.n for g in graphs] if num_points_orig is None else [int(x) for x in num_points_orig]
     labs = [np.empty(g.n, dtype=np.int32) for g in graphs]

@@ -411,6 +411,7 @@ def main():
     ap.add_argument("--cpu-50k", action="store_true", help="cpu_baseline: the single-process 50k-point oracle run on this host (~3 min) even when the pool leg took more than 200 s")
     ap.add_argument("--no-cpu-50k", action="store_true", help="cpu_baseline: skip the single-process 50k-point oracle run on this host")
     ap.add_argument("--batches", type=int, default=0, help="batched calls per GPU per step (default: one per host thread)")
+    ap.add_argument("--builders", type=int, default=1, help="host threads (one context each) that build the affinity graphs of the next batches while the --in-flight threads run the batched cuts (0: every thread builds its own batch's graphs first, as until round 4)")
     ap.add_argument("--window-chunks", type=int, default=0, help="admission window of a batched call in chunks (0: the library's default, 4.8 M rows = 24 chunks): chunks beyond it wait inside the call and join as earlier ones finish")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-inputs", action="store_true", help="skip the pinned-host-input leg (value_host_inputs)")
@@ -468,6 +469,8 @@ def main():
     M = args.batches if args.batches > 0 else K   # batched calls per step, taken from one queue by the K threads
     dev = torch.device("cuda", local_rank)
     ctxs = [api.Context(local_rank) for _ in range(K)]
+    NB = max(0, args.builders)   # builder threads: the graphs of batch k + 1 are built (own context, own stream) while batch k is cut
+    bctxs = [api.Context(local_rank) for _ in range(NB)]
     # The world's chunk list (world*M*B chunks of N_POINTS points) is dealt to the ranks by the LPT rule the
     # map driver uses; chunk c's input is the synthetic chunk of seed c mod M*B, so every rank holds the same
     # M*B different inputs resident in HBM and the per-GPU work is exactly fixed as N grows (weak scaling;
@@ -512,22 +515,27 @@ def main():
     guard_counts = {"restarted_solves": 0, "hist_retries": 0, "accepted_above_limit": 0, "check_timeouts": 0, "calls": 0,
                     "max_true_resid": 0.0, "max_resid_estimate": 0.0, "true_resid_limit": 0.0}
 
-    def one_batch(k, profile=False, only_first=False, from_host=False, w=None, staged=None):
-        # batch k of the rank's M batches, run by host thread w on that thread's context
-        ctx = ctxs[k % K if w is None else w]
+    def build_batch(k, ctx, only_first=False, from_host=False, staged=None):
+        # the affinity graphs of batch k of the rank's M batches, on context `ctx`
         sl = slice(k * B, (k + 1) * B)
         if from_host:
             mine = staged      # the loader thread has put this batch into a device staging block
         else:
             mine = data[sl]
         mine = mine[: 1 if only_first else B]
-        graphs = [api.build_affinity(p, f, alpha=CFG["alpha"], theta=CFG["theta"], gamma=CFG["gamma"], ctx=ctx) for p, f in mine]
+        return [api.build_affinity(p, f, alpha=CFG["alpha"], theta=CFG["theta"], gamma=CFG["gamma"], ctx=ctx) for p, f in mine]
+
+    def one_batch(k, profile=False, only_first=False, from_host=False, w=None, staged=None, graphs=None):
+        # batch k of the rank's M batches, cut by host thread w on that thread's context (its graphs built here unless a builder thread has)
+        ctx = ctxs[k % K if w is None else w]
+        if graphs is None:
+            graphs = build_batch(k, ctx, only_first, from_host, staged)
         try:
             if len(graphs) == 1:
-                lab, ng, st = api.ncuts_labels(graphs[0], N_POINTS, CFG["T"], time_spmv=profile)
+                lab, ng, st = api.ncuts_labels(graphs[0], N_POINTS, CFG["T"], time_spmv=profile, ctx=ctx)
                 labs, ngs = [lab], [ng]
             else:
-                labs, ngs, st = api.ncuts_labels_batch(graphs, None, CFG["T"], time_spmv=profile, window_rows=(args.window_chunks * N_POINTS) or None)
+                labs, ngs, st = api.ncuts_labels_batch(graphs, None, CFG["T"], time_spmv=profile, window_rows=(args.window_chunks * N_POINTS) or None, ctx=ctx)
         finally:
             nnz = graphs[0].nnz
             for g in graphs:
@@ -581,7 +589,11 @@ def main():
             h2d["copies"] += 1
             work.put(job + (i,))
 
-    def worker(w):
+    # With builder threads the jobs pass through them: `work` -> builder (graphs of the batch, on its own context) -> `built` -> worker
+    # (the batched cut).  `built` holds at most K batches ahead of the cuts (12 graphs of 88 MB each per batch).
+    built = queue.Queue(maxsize=max(1, K)) if NB else None
+
+    def builder(bi):
         while True:
             job = work.get()
             if job is None:
@@ -589,6 +601,28 @@ def main():
             step, k, kw = job[:3]
             try:
                 if len(job) == 4:
+                    try:
+                        g = build_batch(k, bctxs[bi], kw.get("only_first", False), True, views(stage_blocks[job[3]]))
+                    finally:
+                        free_blocks.put(job[3])   # (the build has synchronised its stream: the staging block is free again)
+                else:
+                    g = build_batch(k, bctxs[bi], kw.get("only_first", False))
+            except BaseException as e:  # surface the failure in the consuming thread
+                g = e
+            built.put((step, k, kw, g))
+
+    def worker(w):
+        while True:
+            job = (built if NB else work).get()
+            if job is None:
+                return
+            step, k, kw = job[:3]
+            try:
+                if NB:
+                    if isinstance(job[3], BaseException):
+                        raise job[3]
+                    r = one_batch(k, w=w, graphs=job[3], **{a: b for a, b in kw.items() if a != "from_host"})
+                elif len(job) == 4:
                     try:
                         r = one_batch(k, w=w, staged=views(stage_blocks[job[3]]), **kw)
                     finally:
@@ -602,6 +636,7 @@ def main():
                 cv.notify_all()
 
     workers = [threading.Thread(target=worker, args=(w,), daemon=True) for w in range(K)]
+    workers += [threading.Thread(target=builder, args=(bi,), daemon=True) for bi in range(NB)]
     if host:
         workers.append(threading.Thread(target=loader, daemon=True))
     for t in workers:
@@ -752,8 +787,13 @@ def main():
     torch.cuda.empty_cache()
     copy16_gbps = api.bench_copy(ctxs[0], 1 << 30, 10)   # the library's own float4 copy kernel (the guide measures 6.29 TB/s for one)
     barrier()
-    for _ in range(K):
+    for _ in range(NB if NB else K):
         work.put(None)
+    if NB:
+        for t in workers[K:K + NB]:
+            t.join()
+        for _ in range(K):
+            built.put(None)
     uploads.put(None)
     for t in workers:
         t.join()
@@ -786,8 +826,8 @@ def main():
             "ranks": rank_infos,                      # per rank: device, PCI id, GPU NUMA node, CPUs the rank may run on
             "first_collective_ms": first_ms,          # the bounded first RCCL all_reduce (None at N = 1)
             "config": {"workload": "configs[1]: single 200k-point surface chunk, TARL(96-d)+Spatial affinities, "
-                                   f"alpha=1 theta=0.5 T=0.03; per GPU per step {M} batched calls of {B} chunks (one pool of iterating segments each) taken from a queue by {K} host threads",
-                       "n_points": N_POINTS, "nnz": int(nnz), "chunks_per_step": world * M * B, "threads_per_gpu": K, "chunks_per_batch": B, "batches_per_step": M,
+                                   f"alpha=1 theta=0.5 T=0.03; per GPU per step {M} batched calls of {B} chunks (one pool of iterating segments each) taken from a queue by {K} host threads" + (f"; {NB} builder thread(s) build the next batches' affinity graphs meanwhile" if NB else ""),
+                       "n_points": N_POINTS, "nnz": int(nnz), "chunks_per_step": world * M * B, "threads_per_gpu": K, "builder_threads_per_gpu": NB, "chunks_per_batch": B, "batches_per_step": M,
                        "parallelism": f"chunk-dp{world}"},
             "value_host_inputs": (world * M * B * host_steps / elapsed_host) if elapsed_host else None,
             "host_inputs_ratio": (elapsed * host_steps / (elapsed_host * args.steps)) if elapsed_host else None,   # value_host_inputs / value

@@ -880,6 +880,11 @@ def test_run_chunks_equals_one_chunk_at_a_time(api):
     # one thread, one chunk per call: the same again
     again = sharding.run_chunks(args[:3], threads=1, batch=1, alpha=1.0, theta=0.5, gamma=0.0, T=0.03)
     assert all(np.array_equal(a, b) for a, b in zip(again, got[:3]))
+    # the graphs of the next batches are built by builder threads on their own contexts (default: one) and cut on the worker's context:
+    # none, and two, give the same labels
+    for nb in (0, 2):
+        other = sharding.run_chunks(args, threads=2, batch=3, builders=nb, alpha=1.0, theta=0.5, gamma=0.0, T=0.03)
+        assert all(np.array_equal(a, b) for a, b in zip(other, got)), nb
 
 
 def test_device_tensors_in_a_torch_first_process(tmp_path):
