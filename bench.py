@@ -54,7 +54,7 @@ N_POINTS = 200_000
 CFG = dict(alpha=1.0, theta=0.5, gamma=0.0, T=0.03)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 CPU_200K_CACHE = os.path.join(ROOT, "profiles", "r02_cpu_oracle_200k.json")
-PMC_TRAFFIC = [os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic.json") for r in (4, 3, 2)]   # newest first
+PMC_TRAFFIC = [os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic.json") for r in (5, 4, 3, 2)]   # newest first
 
 
 def spmv_bytes(rows: int, nnz: int, launches: int) -> float:
@@ -112,7 +112,28 @@ def _cpu_one_worker(job):
     return _cpu_pool_worker(job)
 
 
-def cpu_baseline(workers: int | None = None, with_50k: bool | None = None):
+def _cpu_device_algorithm_worker(job):
+    """The DEVICE's algorithm (Lanczos on I - L_sym with u1 projected out, component split, the reference's sweep and recursion:
+    tests/gpu_model.py, the NumPy model the GPU suite holds the HIP path to) on one full-size chunk, one core: returns
+    (n, affinity seconds, cut seconds, groups, canonical labels)."""
+    n, seed = job
+    os.environ["OMP_NUM_THREADS"] = "1"
+    os.environ["OPENBLAS_NUM_THREADS"] = "1"
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import gpu_model
+    from autoinst_amd import synth
+    from oracle import ncuts_ref
+    ch = synth.synthetic_chunk(n, seed=seed, tarl=True)
+    t0 = time.perf_counter()
+    A = ncuts_ref.affinity_sparse(ch["points"], ch["tarl"], alpha=CFG["alpha"], theta=CFG["theta"], gamma=CFG["gamma"])
+    t1 = time.perf_counter()
+    sys.setrecursionlimit(10000)
+    groups = gpu_model.normalized_cut_model(A, n, np.arange(n), T=CFG["T"])
+    t2 = time.perf_counter()
+    return n, t1 - t0, t2 - t1, len(groups), ncuts_ref.groups_to_labels(groups, n).astype(np.int32)
+
+
+def cpu_baseline(workers: int | None = None, with_50k: bool | None = None, gpu_labels=None, gpu_seed: int = 0):
     """The oracle beside the GPU number.
 
     (i) `value`: the single-process oracle on the real 200k chunk, measured once in the build container by
@@ -140,6 +161,21 @@ def cpu_baseline(workers: int | None = None, with_50k: bool | None = None):
         with ctx.Pool(1) as pool:
             n50, sec50, g50 = pool.map(_cpu_one_worker, [(50_000, 0)])[0]
         same_box = {"n": n50, "seconds": sec50, "groups": g50, "chunks_per_sec": 1.0 / sec50, "cpu_model": _cpu_model()}
+    # The full 200k-point chunk on THIS host, in seconds instead of hours: the device's own algorithm on one core (the reference's
+    # shift-invert path needs 2.1 h for the same chunk: `value` below).  Its partition is compared with the labels the GPU returned
+    # for the same chunk in this run: a full-size parity check inside the bench.
+    dev_algo = None
+    try:
+        with ctx.Pool(1) as pool:
+            n2, sa, sc, g2, lab2 = pool.map(_cpu_device_algorithm_worker, [(N_POINTS, gpu_seed)])[0]
+        dev_algo = {"n": n2, "affinity_seconds": sa, "cut_seconds": sc, "seconds": sa + sc, "chunks_per_sec": 1.0 / (sa + sc), "groups": g2, "cores": 1,
+                    "cpu_model": _cpu_model(), "what": "tests/gpu_model.py: the device's algorithm in NumPy / SciPy (Lanczos without re-orthogonalisation, "
+                    "component split, the reference's sweep and recursion) on the seed-%d chunk; NOT the reference's shift-invert eigsh path" % gpu_seed}
+        if gpu_labels is not None:
+            from oracle import ncuts_ref
+            dev_algo["partition_equals_gpu_labels"] = bool(ncuts_ref.partitions_equal(lab2, np.asarray(gpu_labels)))
+    except Exception as e:  # noqa: BLE001 -- a reported leg, not the measurement
+        dev_algo = {"error": f"{type(e).__name__}: {e}"}
     pts = sum(r[0] for r in res)
     pool_info = {
         "cores": workers, "host_cores_available": avail, "cpu_model": _cpu_model(),
@@ -149,7 +185,8 @@ def cpu_baseline(workers: int | None = None, with_50k: bool | None = None):
         "per_chunk_seconds_min_max": [min(r[1] for r in res), max(r[1] for r in res)],
         "sample": f"{workers} workers x 1 chunk of {sizes[0]}-{sizes[-1]} points (seeds 0..{workers - 1}), oracle/ncuts_ref.ncuts, 1 BLAS thread each",
     }
-    out = {"unit": "chunks/sec", "kind": "port", "pool": pool_info, "single_process_50k_this_host": same_box}
+    out = {"unit": "chunks/sec", "kind": "port", "pool": pool_info, "single_process_50k_this_host": same_box,
+           "device_algorithm_200k_this_host": dev_algo}
     try:
         with open(CPU_200K_CACHE) as f:
             c = json.load(f)
@@ -880,7 +917,8 @@ def main():
             },
         }
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only: the other ranks would sit in the final barrier
-            out["cpu_baseline"] = cpu_baseline(with_50k=False if args.no_cpu_50k else (True if args.cpu_50k else None))
+            out["cpu_baseline"] = cpu_baseline(with_50k=False if args.no_cpu_50k else (True if args.cpu_50k else None),
+                                               gpu_labels=labs1[0], gpu_seed=my_chunks[0] % (M * B))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -9,7 +9,7 @@ timeout -k 10 900 python bench.py --steps 20 > $O/bench_line.json 2> $O/bench.er
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ov -o ov -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-host-inputs --no-latency-all > $O/bench_overlapped_profiled.json 2> $O/ov.log || exit 2
 python tools/summarize_prof.py $O/ov $O/bench_200k_overlapped > /dev/null && python tools/trace_busy.py $O/ov 0.3 > $O/bench_200k_overlapped_busy.json
 rm -rf $O/ov
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/solo -o solo -- python3 bench.py --steps 10 --warmup 2 --in-flight 1 --batch 12 --no-cpu-baseline --no-host-inputs --no-latency-all > $O/bench_solo_profiled.json 2> $O/solo.log || exit 3
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/solo -o solo -- python3 bench.py --steps 10 --warmup 2 --in-flight 1 --builders 0 --batch 12 --no-cpu-baseline --no-host-inputs --no-latency-all > $O/bench_solo_profiled.json 2> $O/solo.log || exit 3
 python tools/summarize_prof.py $O/solo $O/bench_200k_solo > /dev/null
 rm -rf $O/solo
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pf -o f -- python3 tools/probe_batch_breakdown.py 12 > $O/pmc_f.log 2>&1 || exit 4
