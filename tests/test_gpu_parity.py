@@ -345,6 +345,38 @@ def test_a_spoiled_ritz_pair_is_caught_by_the_true_residual_and_solved_again(api
 
 
 @pytest.mark.gpu
+def test_warm_start_and_hash_start_give_the_same_labels(api, monkeypatch):
+    """Since round 5 a segment with a solved ancestor starts its Lanczos solve from that ancestor's second Ritz vector (carried to its
+    rows by the partitions) instead of the hash vector alone; AI_FLOW_WARM=0 is the hash start of rounds 1-4.  Another start vector,
+    the same eigenvector: the labels are equal -- single chunks (with disconnected segments, whose components inherit through the
+    split), a batched call, a tri-modal chunk -- and the warm start takes fewer steps."""
+    from autoinst_amd import synth
+    cases = [(20000, 3, "tarl", 0.03), (50000, 0, "spatial", 0.075), (30000, 21, "tarl", 0.03), (20000, 2, "tri", 0.005)]
+    graphs = []
+    for n, seed, mode, T in cases:
+        ch = synth.synthetic_chunk(n, seed, tarl=mode != "spatial", dino=mode == "tri")
+        graphs.append((api.build_affinity(ch["points"], ch["tarl"] if mode != "spatial" else None, ch["dino"] if mode == "tri" else None,
+                                          alpha=1.0, theta=0.0 if mode == "spatial" else 0.5, gamma=0.1 if mode == "tri" else 0.0), T))
+    warm = [api.ncuts_labels(g, g.n, T) for g, T in graphs]
+    warm_b = api.ncuts_labels_batch([g for g, _ in graphs[:3:2]], None, 0.03)
+    monkeypatch.setenv("AI_FLOW_WARM", "0")
+    steps_w = steps_h = 0
+    for (g, T), (lab1, ng1, st1) in zip(graphs, warm):
+        lab0, ng0, st0 = api.ncuts_labels(g, g.n, T)
+        assert ng0 == ng1 and np.array_equal(lab0, lab1), (g.n, ng0, ng1)
+        assert st0["lanczos_solves"] == st1["lanczos_solves"] and st0["unconverged"] == st1["unconverged"] == 0
+        assert st1["max_true_resid"] <= 2e-10 and st0["max_true_resid"] <= 2e-10
+        steps_w += st1["spmv_rows"]
+        steps_h += st0["spmv_rows"]
+    hash_b = api.ncuts_labels_batch([g for g, _ in graphs[:3:2]], None, 0.03)
+    monkeypatch.delenv("AI_FLOW_WARM")
+    assert hash_b[1] == warm_b[1] and all(np.array_equal(a, b) for a, b in zip(hash_b[0], warm_b[0]))
+    assert steps_w < 0.97 * steps_h, (steps_w, steps_h)   # rows x steps: ~8 % fewer
+    for g, _ in graphs:
+        g.free()
+
+
+@pytest.mark.gpu
 def test_level_synchronous_driver_gives_the_same_labels(tmp_path):
     """The level-synchronous driver of rounds 1-2 (test-only build libautoinst_hip_lockstep.so, AI_NCUT_LOCKSTEP=1) and the
     asynchronous frontier of the shipped library give identical labels: same solver arithmetic per segment, same sweep, same

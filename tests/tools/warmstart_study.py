@@ -152,7 +152,7 @@ def run_variant(A, n, T, variant, inherit=True):
             if not extra and not with_f:
                 wv = None
         if dev and wv is not None:
-            wv = wv * np.sqrt(nn) + 0.01 * gm.start_vector(lab)
+            wv = wv * np.sqrt(nn) + float(os.environ.get("WS_EPS", "0.01")) * gm.start_vector(lab)
         rec(w[mask][:, mask], lab[mask], None if wv is None else wv[mask])
         rec(w[~mask][:, ~mask], lab[~mask], None if wv is None else wv[~mask])
 
