@@ -10,7 +10,9 @@ eigenvector with its own deterministic solver:
 * disconnected segment -> split into its connected components in one step (`split_components`: what the
   reference's recursion does to it, one component per ``eigsh`` call);
 
-then exactly the reference's 10-threshold sweep and recursion.  This file restates
+then exactly the reference's 10-threshold sweep and recursion.  (Since round 5 the device starts a segment with a solved ancestor
+from that ancestor's second Ritz vector instead of the hash vector alone; the model keeps the hash start -- another start vector, the
+same eigenvector -- and the GPU tests that demand equal partitions between device and model hold that equality.)  This file restates
 that algorithm in NumPy, segment by segment, so that (a) the algorithm can be checked
 against the oracle / goldens without a GPU and (b) GPU tests can demand *bit-for-bit
 equal partitions* between device and model on inputs where SciPy's own answer is
