@@ -106,11 +106,14 @@ def run_variant(A, n, T, variant, inherit=True):
     dev = variant.startswith("dev")   # devP: like pP, but what the device would form: (sum of the Ritz vectors)|child * sqrt(n_parent) + 0.01 * hash
     if dev:
         variant = "p" + variant[3:]
+    free = variant.endswith("free")   # rrKfree: the K extra products of the Rayleigh-Ritz start are NOT counted (the ceiling of that form)
+    if free:
+        variant = variant[:-4]
     rr = variant.startswith("rr")    # rrK: Rayleigh-Ritz in the child over the parent's K top Ritz vectors (Fiedler included), K extra SpMVs
     with_f = variant.endswith("f") or rr
     p = 0 if hashv else int(variant[2:]) + 1 if rr else int(variant[1:].rstrip("f"))
     n_extra = 0 if hashv else max(p - 2, 0)
-    st = {"variant": ("dev" + variant[1:]) if dev else variant, "solves": 0, "steps": 0, "row_steps": 0, "warm_solves": 0, "per_solve": []}
+    st = {"variant": (("dev" + variant[1:]) if dev else variant) + ("free" if free else ""), "solves": 0, "steps": 0, "row_steps": 0, "warm_solves": 0, "per_solve": []}
     groups = []
 
     def rec(w, lab, warm):
@@ -132,6 +135,8 @@ def run_variant(A, n, T, variant, inherit=True):
             warm = rr_start(w, warm)
         ev, m, resid, d, fied, extra = lanczos(w, lab, start=warm, n_extra=n_extra)
         st["solves"] += 1
+        if free:
+            extra_steps = 0
         st["steps"] += m + extra_steps
         st["row_steps"] += nn * (m + extra_steps)
         st["warm_solves"] += warm is not None
