@@ -50,6 +50,40 @@ def rr_start(w, cols):
     return Q @ Z[:, -1]
 
 
+def rr_start_device_form(w, cols, ids, eps=float(os.environ.get("WS_RR_EPS", "1e-3"))):
+    """`rr_start` as a device would form it: ONE pass over the child's entries gives Z = M Q (an SpMM with K vectors) and the raw sums
+    a = Q^T u1, G = Q^T Q, H = Q^T Z; the projection of u1 is algebra (M u1 = u1: G~ = G - a a^T, H~ = H - a a^T); the K x K generalised
+    problem H~ c = theta G~ c is solved after dropping the directions of G~ below 1e-10 of its largest eigenvalue; the start vector is
+    sum_k c_k q_k - (c . a) u1 + eps * hash."""
+    n = w.shape[0]
+    d = np.asarray(w.sum(axis=0)).ravel() + 1.0
+    s = 1.0 / np.sqrt(d)
+    Wm = (sp.diags(s) @ (w + sp.identity(n)) @ sp.diags(s)).tocsr()
+    u1 = np.sqrt(d / d.sum())
+    Q = cols * np.sqrt(n)          # entries of order 1
+    a = Q.T @ u1
+    if os.environ.get("WS_RR_TWO_PASS") == "1":
+        # two passes: the u1 components first, then everything on the PROJECTED vectors (no cancellation in G~ / H~)
+        Qp = Q - np.outer(u1, a)
+        Z = Wm @ Qp
+        G = Qp.T @ Qp
+        H = Qp.T @ Z
+    else:
+        Z = Wm @ Q
+        G = Q.T @ Q - np.outer(a, a)
+        H = Q.T @ Z - np.outer(a, a)
+    G = 0.5 * (G + G.T)
+    H = 0.5 * (H + H.T)
+    lam, U = np.linalg.eigh(G)
+    keep = lam > 1e-10 * lam.max()
+    if not keep.any():
+        return None
+    T = U[:, keep] / np.sqrt(lam[keep])      # G~-orthonormal basis
+    th, Y = np.linalg.eigh(T.T @ H @ T)
+    c = T @ Y[:, -1]
+    return (Q @ c - (c @ a) * u1) * np.sqrt(n) + eps * gm.start_vector(ids)   # (Q c has unit norm: entries of order 1 before the hash admixture)
+
+
 def lanczos(w, ids, start=None, tol=1e-10, max_iter=4000, n_extra=0):
     """gm.lanczos_fiedler with a given start vector; also returns `n_extra` further Ritz vectors (ranks 1 ..) with their Ritz values."""
     n = w.shape[0]
@@ -106,6 +140,9 @@ def run_variant(A, n, T, variant, inherit=True):
     dev = variant.startswith("dev")   # devP: like pP, but what the device would form: (sum of the Ritz vectors)|child * sqrt(n_parent) + 0.01 * hash
     if dev:
         variant = "p" + variant[3:]
+    devrr = variant.startswith("rrdev")   # rrdevK: the Rayleigh-Ritz start in the form a device would compute (rr_start_device_form); K products counted as 3 steps (one SpMM pass)
+    if devrr:
+        variant = "rr" + variant[5:]
     free = variant.endswith("free")   # rrKfree: the K extra products of the Rayleigh-Ritz start are NOT counted (the ceiling of that form)
     if free:
         variant = variant[:-4]
@@ -113,7 +150,7 @@ def run_variant(A, n, T, variant, inherit=True):
     with_f = variant.endswith("f") or rr
     p = 0 if hashv else int(variant[2:]) + 1 if rr else int(variant[1:].rstrip("f"))
     n_extra = 0 if hashv else max(p - 2, 0)
-    st = {"variant": (("dev" + variant[1:]) if dev else variant) + ("free" if free else ""), "solves": 0, "steps": 0, "row_steps": 0, "warm_solves": 0, "per_solve": []}
+    st = {"variant": (("dev" + variant[1:]) if dev else variant) + ("free" if free else "") + ("(device form)" if devrr else ""), "solves": 0, "steps": 0, "row_steps": 0, "warm_solves": 0, "per_solve": []}
     groups = []
 
     def rec(w, lab, warm):
@@ -131,8 +168,8 @@ def run_variant(A, n, T, variant, inherit=True):
             return
         extra_steps = 0
         if rr and warm is not None:
-            extra_steps = warm.shape[1]
-            warm = rr_start(w, warm)
+            extra_steps = 3 if devrr else warm.shape[1]
+            warm = rr_start_device_form(w, warm, lab) if devrr else rr_start(w, warm)
         ev, m, resid, d, fied, extra = lanczos(w, lab, start=warm, n_extra=n_extra)
         st["solves"] += 1
         if free:
